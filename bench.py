@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""bench.py -- Mray/s of the ray-trace hot path on MI355X (BASELINE.json metric).
+
+One "step" = one frame of the hot path (rt_render_frame through the C ABI) over the synthetic
+workload of BASELINE.json configs[1]: procedural bunny stand-in (81 920 triangles, median-split
+BVH), 1920x1080, 4 spp, one bounce (GI) + AO, Sky_01 environment, default RenderParams, static
+camera, frame indices continuing from the warm-up.  Inputs are resident in HBM before the timed
+region.  Headline camera = the close-up of SURVEY.md 8d (mesh ~45 % of the frame); the
+reference's default camera (mesh < 1 % of the frame) is reported beside it in "default_camera".
+
+N > 1 (launched by torch.distributed.run, one process per GPU): the frame's 16x16 tiles are dealt
+round-robin to the ranks (weak... no: the frame is fixed, so this is STRONG scaling), every rank
+holds a BVH replica, and each frame ends with one RCCL gather of COLOR0 to rank 0 over xGMI plus
+the un-tiling kernel.  value = rays of the whole frame / max-over-ranks time.
+
+A "ray" is one traceBVH / traceBVHShadow call of the reference's shader for this frame
+(SURVEY.md 8d), counted by the library's work counters in a separate, untimed pass and checked
+against the oracle's count on the CPU sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+for p in (str(ROOT), str(ROOT / "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+W, H, SPP = 1920, 1080, 4
+
+
+def algorithmic_bytes(c, npix):
+    """SURVEY.md 8d / BASELINE.md: reference-layout bytes of one frame."""
+    return 48 * c.nodeFetch + 48 * c.triFetch + npix * 36 + 12 * c.envLookup
+
+
+class _DevArray:
+    """Wrap a raw device pointer for torch.as_tensor via the CUDA array interface (no copy)."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes // 2,), "typestr": "<i2", "data": (ptr, False), "version": 2}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--subdiv", type=int, default=6, help="icosphere subdivisions of the bunny stand-in (6 = 81 920 tris)")
+    ap.add_argument("--pipeline", default="auto", choices=["auto", "mega", "wave"])
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the oracle (CPU baseline) sample; 0 = skip")
+    ap.add_argument("--no-default-camera", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import opengl_raytracing_amd as rt
+    import scenes
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    pipeline = {"auto": rt.RT_PIPELINE_AUTO, "mega": rt.RT_PIPELINE_MEGAKERNEL, "wave": rt.RT_PIPELINE_WAVEFRONT}[args.pipeline]
+    nodes, tris = scenes.bunny_bvh(args.subdiv)
+    faces = scenes.env_faces("Sky_01")
+    params = rt.default_render_params()
+    params.sppPerFrame = SPP
+    npix = W * H
+
+    def make_renderer(count):
+        r = rt.Renderer(device=local_rank, rank=rank, world_size=world, pipeline=pipeline, count_work=count)
+        r.upload_bvh(nodes, tris)
+        r.upload_env(faces)
+        r.resize(W, H)
+        return r
+
+    def uniforms(cam, frame):
+        return rt.frame_uniforms(params, cam, W, H, frame, True, nodes.shape[0], tris.shape[0])
+
+    def run_camera(cam, steps, warmup, timed_stage=True):
+        """-> dict(ms_per_step, counters summed over the timed frames (this rank), stage times)"""
+        # untimed counting pass over the same frame indices (work counters slow the kernels down)
+        rc = make_renderer(True)
+        for f in range(warmup):
+            rc.render_frame(uniforms(cam, f))
+        rc.reset_counters()
+        for f in range(warmup, warmup + steps):
+            rc.render_frame(uniforms(cam, f))
+        cnt = rc.counters()
+        rc.close()
+
+        ren = make_renderer(False)
+        ext = torch.cuda.ExternalStream(ren.stream(), device=torch.device("cuda", local_rank))
+        gathered = frame_out = None
+        locals_ = None
+        if world > 1:
+            blk = ren.gather_block_bytes(rt.RT_TARGET_COLOR)
+            if rank == 0:
+                gathered = torch.empty((world, blk // 2), dtype=torch.int16, device="cuda")
+                frame_out = torch.empty((H, W, 4), dtype=torch.int16, device="cuda")
+
+        def step(f):
+            ren.render_frame(uniforms(cam, f))
+            if world > 1:
+                ptr, nbytes = ren.local_target(rt.RT_TARGET_COLOR)
+                loc = torch.as_tensor(_DevArray(ptr, nbytes), device="cuda")
+                with torch.cuda.stream(ext):
+                    dist.gather(loc, list(gathered.unbind(0)) if rank == 0 else None, dst=0)
+                    if rank == 0:
+                        ren.assemble_gathered(rt.RT_TARGET_COLOR, gathered.data_ptr(), frame_out.data_ptr())
+
+        for f in range(warmup):
+            step(f)
+        ren.synchronize()
+        torch.cuda.synchronize()
+        if timed_stage:
+            ren.enable_stage_timing(True)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for f in range(warmup, warmup + steps):
+            step(f)
+        ren.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        stages = ren.stage_times() if timed_stage else None
+        ren.close()
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        cc = torch.tensor(list(cnt.to_dict().values()), dtype=torch.int64, device="cuda")
+        if world > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dist.all_reduce(cc, op=dist.ReduceOp.SUM)
+        total = rt.RtCounters(*[int(v) for v in cc.tolist()])
+        return {"seconds": float(tt.item()), "counters": total, "local_counters": cnt, "stages": stages}
+
+    closeup = run_camera(scenes.camera("closeup"), args.steps, args.warmup)
+    res = closeup
+    rays = res["counters"].rays
+    mray = rays / res["seconds"] / 1e6
+    ms_per_step = res["seconds"] / args.steps * 1e3
+
+    # roofline of the dominant kernel (stage with the largest device time on this rank)
+    roofline = None
+    st = res["stages"]
+    if st and st["stages"]:
+        name, dom = max(st["stages"].items(), key=lambda kv: kv[1]["ms"])
+        launches = max(int(dom["launches"]), 1)
+        avg_ms = dom["ms"] / launches
+        lc = res["local_counters"]
+        # algorithmic bytes of this rank's share of one frame, all attributed to the pipeline's kernels;
+        # with one kernel per frame (megakernel) that is exactly the kernel's bytes per launch.
+        bytes_per_frame = algorithmic_bytes(lc, npix // world) / args.steps
+        share = dom["ms"] / max(sum(v["ms"] for v in st["stages"].values()), 1e-9)
+        bytes_per_launch = bytes_per_frame * (1.0 if len(st["stages"]) == 1 else share) * args.steps / launches
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms, "launches": launches,
+                    "algorithmic_bytes_per_launch": bytes_per_launch,
+                    "note": "BVH (5.5 MB) is L2/Infinity-Cache resident: algorithmic bytes/s may exceed HBM peak; see DESIGN.md"}
+
+    out = {
+        "metric": "Mray/s @1080p 4spp bunny BVH", "value": mray, "unit": "Mray/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[1]: procedural bunny stand-in (icosphere subdiv %d, %d tris, median-split BVH), 1920x1080, "
+                               "4 spp, GI 1 bounce + AO 4, Sky_01 env, close-up camera (-2,1.5,1.0)" % (args.subdiv, tris.shape[0]),
+                   "pipeline": args.pipeline, "tiles": "16x16 round-robin over ranks" if world > 1 else "single GPU",
+                   "rays_per_frame": rays // args.steps, "msample_per_s": npix * SPP * args.steps / res["seconds"] / 1e6,
+                   "hit_pixels": res["counters"].hitPixels // args.steps},
+        "roofline": roofline,
+    }
+    if st:
+        out["stage_ms_per_frame"] = {k: v["ms"] / args.steps for k, v in st["stages"].items()}
+
+    if not args.no_default_camera:
+        d = run_camera(scenes.camera("default"), args.steps, args.warmup, timed_stage=False)
+        out["default_camera"] = {"value": d["counters"].rays / d["seconds"] / 1e6, "unit": "Mray/s",
+                                 "ms_per_step": d["seconds"] / args.steps * 1e3, "rays_per_frame": d["counters"].rays // args.steps,
+                                 "hit_pixels": d["counters"].hitPixels // args.steps}
+
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        import oracle as orc
+        cores = os.cpu_count() or 1
+        cam = scenes.camera("closeup")
+        u = uniforms(cam, args.warmup)
+        # calibrate on 4 rows through the middle of the mesh, then take as many rows as fit the budget
+        t0 = time.perf_counter()
+        _, c0 = orc.render(u, nodes, tris, faces, None, region=(0, H // 2, W, H // 2 + 4), nthreads=cores)
+        cal = time.perf_counter() - t0
+        rows = int(max(4, min(H, 4 * args.cpu_seconds / max(cal, 1e-3))))
+        y0 = max(0, H // 2 - rows // 2)
+        t0 = time.perf_counter()
+        _, c1 = orc.render(u, nodes, tris, faces, None, region=(0, y0, W, y0 + rows), nthreads=cores)
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": c1.rays / dt / 1e6, "unit": "Mray/s", "cores": cores, "kind": "port",
+                               "sample": f"oracle (scalar fp32 C++ restatement, -O2), rows {y0}..{y0 + rows} of the same 1080p/4spp "
+                                         f"close-up frame {args.warmup}, {c1.rays} rays in {dt:.1f} s on {cores} threads"}
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,250 @@
+/* include/rt_mi355.h -- C ABI of librt_mi355.so, the MI355X (gfx950) drop-in for the reference's
+ * ray-trace pass.
+ *
+ * The reference (Darky-The-Dragon/OpenGL-RayTracing) has no plugin/FFI seam; the narrowest one is
+ *     void renderRay(AppState&, int fbw, int fbh, bool cameraMoved,
+ *                    const glm::mat4& currView, const glm::mat4& currProj);     include/render/render.h:19
+ * whose real contract is "set ~75 uniforms, bind 4 resources, draw one full-screen triangle"
+ * (src/render/render.cpp:55-194).  Each entry point below names the reference interface it replaces.
+ * INTEGRATION.md shows the call-site a maintainer would change.
+ *
+ * Conventions: plain pointers and sizes, no C++/torch types; every function returns RT_OK (0) or a
+ * negative RtStatus and never throws; the caller owns all host pointers and the library copies
+ * during the call; one context is driven from one thread at a time; the library owns device
+ * memory and its HIP stream.  Matrices are column-major float[16] (glm / glUniformMatrix4fv with
+ * transpose = GL_FALSE, src/render/Shader.cpp:190-192).  Images are row-major with ROW 0 = BOTTOM
+ * row (GL window origin, what glReadPixels returns).
+ */
+#ifndef RT_MI355_H
+#define RT_MI355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum RtStatus {
+    RT_OK = 0,
+    RT_ERR_INVALID = -1,      /* bad argument */
+    RT_ERR_NO_DEVICE = -2,    /* no HIP device / HIP runtime unusable: the product path never falls back to a CPU */
+    RT_ERR_HIP = -3,          /* a HIP call failed; rt_last_error() has the text */
+    RT_ERR_STATE = -4,        /* call order (e.g. render before resize) */
+    RT_ERR_UNSUPPORTED = -5,  /* valid request this build cannot serve (stated in the message) */
+    RT_ERR_IO = -6            /* file could not be read / parsed */
+} RtStatus;
+
+/* The uniform block of the ray-trace program: shaders/rt/rt_uniforms.glsl:25-177, same order.
+ * All members are 4 bytes wide, so the struct has no padding. */
+typedef struct RtUniforms {
+    float eps, pi, inf;                                   /* uEPS uPI uINF  (RenderParams.h:229-231) */
+    float camPos[3], camRight[3], camUp[3], camFwd[3];
+    float tanHalfFov, aspect;
+    int32_t frameIndex;                                   /* set by the library from its accumulation state */
+    int32_t spp;
+    float resolution[2];
+    float jitter[2];
+    int32_t enableJitter;
+    int32_t useBVH, nodeCount, triCount;
+    int32_t showMotion;
+    float prevViewProj[16], currViewProj[16];
+    int32_t cameraMoved;
+    float taaStillThresh, taaHardMovingThresh;
+    float taaHistoryMinWeight, taaHistoryAvgWeight, taaHistoryMaxWeight, taaHistoryBoxSize;
+    int32_t enableTAA;
+    float giScaleAnalytic, giScaleBVH;
+    int32_t enableGI, enableAO, aoSamples;
+    float aoRadius, aoBias, aoMin;
+    int32_t useEnvMap;
+    float envIntensity;
+    int32_t sunEnabled;
+    float sunColor[3], sunIntensity, sunDir[3];
+    int32_t skyEnabled;
+    float skyColor[3], skyIntensity, skyUpDir[3];
+    int32_t pointLightEnabled;
+    float pointLightPos[3], pointLightColor[3], pointLightIntensity;
+    float matAlbedoColor[3], matAlbedoSpecStrength, matAlbedoGloss;
+    float matGlassAlbedo[3], matGlassIOR, matGlassDistortion;
+    int32_t matGlassEnabled;
+    float matMirrorAlbedo[3], matMirrorGloss;
+    int32_t matMirrorEnabled;
+} RtUniforms;
+
+/* include/render/RenderParams.h:14-239, same order and defaults (rt_default_render_params). */
+typedef struct RtRenderParams {
+    int32_t sppPerFrame; float exposure;
+    float matAlbedoColor[3], matAlbedoSpecStrength, matAlbedoGloss;
+    int32_t matGlassEnabled; float matGlassColor[3], matGlassIOR, matGlassDistortion;
+    int32_t matMirrorEnabled; float matMirrorColor[3], matMirrorGloss;
+    int32_t enableJitter; float jitterStillScale, jitterMovingScale;
+    int32_t enableGI; float giScaleAnalytic, giScaleBVH;
+    int32_t enableEnvMap; float envMapIntensity;
+    int32_t sunEnabled; float sunColor[3], sunIntensity, sunYaw, sunPitch;
+    int32_t skyEnabled; float skyColor[3], skyIntensity, skyYaw, skyPitch;
+    int32_t pointLightEnabled; float pointLightColor[3], pointLightIntensity, pointLightPos[3];
+    int32_t pointLightOrbitEnabled; float pointLightOrbitRadius, pointLightOrbitSpeed, pointLightYaw, pointLightPitch;
+    int32_t enableAO, aoSamples; float aoRadius, aoBias, aoMin;
+    int32_t enableTAA; float taaStillThresh, taaHardMovingThresh, taaHistoryMinWeight, taaHistoryAvgWeight,
+        taaHistoryMaxWeight, taaHistoryBoxSize;
+    int32_t enableSVGF; float svgfVarMax, svgfKVar, svgfKColor, svgfKVarMotion, svgfKColorMotion, svgfStrength;
+    float motionScale;
+} RtRenderParams;
+
+/* Camera state, include/io/Camera.h:21-109 (degrees). */
+typedef struct RtCamera { float pos[3], yaw, pitch, fov, aspect; } RtCamera;
+
+/* Work counters in the reference's units: a "ray" is one call of traceBVH /
+ * traceBVHShadow / traceAnalyticCore; node/tri fetches are nodeFetch()/triFetch() calls of
+ * shaders/rt/rt_bvh.glsl (48 B each in the reference layout). */
+typedef struct RtCounters {
+    uint64_t raysClosest, raysShadow, raysAnalytic, nodeFetch, triFetch, envLookup, hitPixels;
+} RtCounters;
+
+typedef enum RtPipeline {
+    RT_PIPELINE_AUTO = 0,       /* wavefront pipeline for BVH scenes, megakernel for the analytic scene */
+    RT_PIPELINE_MEGAKERNEL = 1, /* one thread per pixel, the whole fragment program in one kernel */
+    RT_PIPELINE_WAVEFRONT = 2   /* staged: primary -> ray generation -> persistent traversal -> combine */
+} RtPipeline;
+
+typedef struct RtDeviceConfig {
+    int32_t device;        /* HIP device ordinal */
+    int32_t rank;          /* tile-parallel rank of this context, 0 <= rank < worldSize */
+    int32_t worldSize;     /* number of GPUs sharing one frame (1 = whole frame here) */
+    int32_t pipeline;      /* RtPipeline */
+    int32_t countWork;     /* non-zero: kernels maintain RtCounters (slower) */
+    int32_t reserved[3];
+} RtDeviceConfig;
+
+typedef struct RtContext RtContext;
+
+enum { RT_TARGET_COLOR = 0, RT_TARGET_MOTION = 1, RT_TARGET_GPOS = 2, RT_TARGET_GNRM = 3 };  /* rt.frag:29-38 */
+enum { RT_FORMAT_F16 = 0, RT_FORMAT_F32 = 1 };
+
+#define RT_TILE_DIM 16               /* framebuffer tiles are RT_TILE_DIM x RT_TILE_DIM pixels */
+#define RT_TILE_PIXELS 256
+
+/* ---------------------------------------------------------------- device side */
+
+/* Replaces: GL context + FBO/texture creation (Application::initGLResources, application.cpp:195-205). */
+int rt_create(const RtDeviceConfig *cfg, RtContext **out);
+void rt_destroy(RtContext *ctx);
+const char *rt_last_error(const RtContext *ctx);   /* ctx may be NULL: error of the last failed rt_create */
+
+/* Replaces upload_bvh_tbo (include/scene/bvh.h:121, src/scene/bvh.cpp:141-221): takes the reference's
+ * two RGBA32F texture-buffer payloads (12 floats per node, 12 per triangle) and repacks them into
+ * the device layout.  nNodes == 0 / nTris == 0 clears the scene. */
+int rt_upload_bvh(RtContext *ctx, const float *nodes12, int nNodes, const float *tris12, int nTris);
+
+/* Replaces the glTexImage2D face uploads of loadCubeMapFromCross / createDummyCubeMap
+ * (src/render/cubemap.cpp:7-31, 67-91): 6 faces in GL order +X -X +Y -Y +Z -Z, faceSize^2 texels of
+ * `channels` (3 or 4) bytes, rows in upload order.  faces == NULL installs the 1x1 dummy
+ * (128,128,255) of cubemap.cpp:13. */
+int rt_upload_env(RtContext *ctx, const uint8_t *faces, int faceSize, int channels);
+
+/* Replaces Accum::recreate + GBuffer::recreate (src/render/accum.cpp:106-, gbuffer.cpp:12-53):
+ * allocates COLOR0 ping-pong (RGBA16F), motion (RG16F), world pos / normal (RGBA16F); clears
+ * history; frameIndex = 0. */
+int rt_resize(RtContext *ctx, int width, int height);
+
+/* Replaces Accum::reset (src/render/accum.cpp:98-102). */
+int rt_reset_accum(RtContext *ctx);
+
+/* accum.frameIndex (include/render/accum.h:125-128): the value the next frame will see as uFrameIndex. */
+int rt_frame_index(const RtContext *ctx);
+
+/* Replaces the ray pass of renderRay (src/render/render.cpp:58-194 + swapAfterFrame :242; the present
+ * pass :199-239 is not part of this path).  `u` is the uniform block; u->frameIndex is ignored and
+ * replaced by rt_frame_index().  Asynchronous on the context's stream. */
+int rt_render_frame(RtContext *ctx, const RtUniforms *u);
+
+/* The reference call-site in one call: mainLoop steps application.cpp:381-405 + renderRay + endFrame
+ * (:459).  Keeps FrameState (prev/curr view-projection) inside the context.  currView/currProj may
+ * be NULL: they are then derived from `cam` (Camera.cpp:66-73). */
+int rt_render_ray(RtContext *ctx, const RtRenderParams *params, const RtCamera *cam, int useBVH, int showMotion,
+                  const float *currView, const float *currProj);
+
+int rt_synchronize(RtContext *ctx);
+
+/* Read one render target of the last frame into host memory: full width x height image, row 0 =
+ * bottom, channels 4/2/4/4, as half bit patterns (RT_FORMAT_F16) or floats (RT_FORMAT_F32, exact
+ * widening).  With worldSize > 1 only this rank's tiles are filled, the rest is zero. */
+int rt_read_target(RtContext *ctx, int which, void *dst, int dstFormat);
+
+/* Tile-parallel plumbing for the RCCL gather (one process per GPU; the collective itself is
+ * issued by the host through torch.distributed / RCCL on these device pointers).
+ * Local layout: [localTile][RT_TILE_PIXELS][channels] halfs, localTile = globalTile / worldSize for
+ * globalTile % worldSize == rank, globalTile = tileY * tilesX + tileX. */
+int rt_local_target(RtContext *ctx, int which, void **devPtr, size_t *bytes);
+/* bytes every rank must contribute so that all ranks send equally sized blocks (padded local size) */
+int rt_gather_block_bytes(const RtContext *ctx, int which, size_t *bytes);
+/* On the gathering rank: gatheredDev holds worldSize blocks of rt_gather_block_bytes() in rank order;
+ * writes the row-major full frame (halfs) to dstDev (device memory, width*height*channels*2 bytes). */
+int rt_assemble_gathered(RtContext *ctx, int which, const void *gatheredDev, void *dstDev);
+/* the context's HIP stream (hipStream_t) so a caller can order its own work after the frame */
+int rt_stream(RtContext *ctx, void **hipStream);
+
+int rt_get_counters(RtContext *ctx, RtCounters *out);   /* needs countWork; totals since rt_reset_counters */
+int rt_reset_counters(RtContext *ctx);
+
+/* Device timing of the dominant kernel(s): HIP events recorded on the context's stream around each
+ * stage of every frame since the last reset.  stage names: rt_stage_name(i). */
+#define RT_MAX_STAGES 12
+typedef struct RtStageTimes { int32_t nStages; int32_t frames; double ms[RT_MAX_STAGES]; uint64_t launches[RT_MAX_STAGES]; } RtStageTimes;
+int rt_enable_stage_timing(RtContext *ctx, int enable);
+int rt_get_stage_times(RtContext *ctx, RtStageTimes *out);   /* synchronises */
+const char *rt_stage_name(int stage);
+
+/* Diagnostics used by the parity tests: evaluate one device function of the float model on arrays
+ * (op: 0 sin, 1 cos, 2 exp2, 3 log2, 4 pow(a,b), 5 f32->f16 bits, 6 rand(a,b,frame=c) bits,
+ * 7 a/b, 8 sqrt(a), 9 1/sqrt(a)).  Arrays are host memory of n floats (out: n uint32 bit patterns). */
+int rt_debug_eval(RtContext *ctx, int op, const float *a, const float *b, const float *c, uint32_t *out, int n);
+/* Trace n rays against the uploaded BVH with the device traversal: kind 0 = closest hit (out: t, then
+ * hit point xyz, then normal xyz; t = inf on miss), kind 1 = any hit within tMax (out[0] = 1/0). */
+int rt_debug_trace(RtContext *ctx, int kind, const float *origins, const float *dirs, const float *tMax, float eps,
+                   float inf, float *out7, int n);
+
+/* ---------------------------------------------------------------- host side (no GPU needed) */
+
+void rt_default_render_params(RtRenderParams *p);      /* include/render/RenderParams.h:20-238 */
+void rt_default_camera(RtCamera *c);                   /* include/app/state.h:129-131 */
+void rt_default_bvh_transform(float *M16);             /* include/app/state.h:26-31 */
+void rt_camera_view(const RtCamera *c, float *V16);    /* Camera::GetViewMatrix, src/io/Camera.cpp:66-68 */
+void rt_camera_proj(const RtCamera *c, float *P16);    /* Camera::GetProjectionMatrix, :71-73 */
+void rt_mat4_mul(const float *A16, const float *B16, float *out16);   /* FrameState::beginFrame P*V, frame_state.h:71 */
+void rt_generate_jitter(int frameIndex, float *out2);  /* generateJitter2D, src/app/application.cpp:42-47 */
+int rt_camera_moved(const float *currVP16, const float *prevVP16);    /* application.cpp:387-395 */
+
+/* The glUniform* block of renderRay, src/render/render.cpp:67-167, with the jitter policy of
+ * application.cpp:398-405.  envLoaded = (app.envMapTex != 0). */
+void rt_make_uniforms(const RtRenderParams *p, const RtCamera *cam, const float *currView, const float *currViewProj,
+                      const float *prevViewProj, int fbw, int fbh, int frameIndex, int cameraMoved, int useBVH,
+                      int showMotion, int nodeCount, int triCount, int envLoaded, RtUniforms *out);
+
+/* gather_model_triangles (include/scene/bvh.h:135, src/scene/bvh.cpp:225-246): 9 floats (v0,e1,e2) per
+ * index triple after the model matrix.  Returns the triangle count. */
+int rt_gather_triangles(const float *positions, const uint32_t *indices, int nIdx, const float *M16, float *outTris9);
+
+/* build_bvh (include/scene/bvh.h:102, src/scene/bvh.cpp:94-137) + the packing half of upload_bvh_tbo
+ * (:147-204).  nodes12 needs room for 2*nTris*12 floats, tris12 for nTris*12.  Returns the node count. */
+int rt_build_bvh(const float *tris9, int nTris, float *nodes12, float *tris12);
+
+/* Stand-in for Model/Mesh + Assimp (include/scene/model.h:105-228) for plain .obj files: v / f records,
+ * fan triangulation, negative indices.  Buffers are malloc'ed; release with rt_free. */
+int rt_load_obj(const char *path, float **positions, int *nVerts, uint32_t **indices, int *nIdx);
+/* PNG decode (8-bit RGB / RGBA / grey, non-interlaced; zlib) standing in for stbi_load at cubemap.cpp:40 */
+int rt_load_png(const char *path, uint8_t **pixels, int *width, int *height, int *channels);
+void rt_free(void *p);
+
+/* The 4x3 cross slicing of loadCubeMapFromCross (src/render/cubemap.cpp:47-91).  faces needs
+ * 6*(height/3)^2*channels bytes.  Returns faceSize, 0 if the image is not a valid cross. */
+int rt_cubemap_from_cross(const uint8_t *img, int width, int height, int channels, uint8_t *faces);
+
+int rt_sizeof_uniforms(void);
+int rt_sizeof_render_params(void);
+const char *rt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_MI355_H */

@@ -1,0 +1,615 @@
+// rt_api.hip -- C ABI of librt_mi355.so (include/rt_mi355.h): context, uploads, frame loop, readback.
+//
+// The context owns one HIP stream and all device memory.  There is no CPU rendering path: without
+// a usable HIP device rt_create fails with RT_ERR_NO_DEVICE and nothing else can be called.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_mi355.h"
+#include "rt_frame.hpp"
+#include "rt_wave.hpp"
+
+using namespace rtd;
+
+static thread_local std::string g_createError;
+
+struct StageEvent { int stage; hipEvent_t a, b; };
+
+struct RtContext {
+    RtDeviceConfig cfg{};
+    hipStream_t stream = nullptr;
+    std::string err;
+    // scene
+    float4 *dWNodes = nullptr, *dTris = nullptr;
+    uchar4 *dEnv = nullptr;
+    int envSize = 0;
+    int nNodes = 0, nTris = 0, nInner = 0, rootRef = 0, treeDepth = 0;
+    float rootMin[3] = {0, 0, 0}, rootMax[3] = {0, 0, 0};
+    // frame state
+    FrameGeom g{};
+    bool sized = false;
+    uint2 *dColor[2] = {nullptr, nullptr};
+    uint32_t *dMotion = nullptr;
+    uint2 *dGPos = nullptr, *dGNrm = nullptr;
+    size_t nSlots = 0;
+    int frameIndex = 0, writeIdx = 0;     // include/render/accum.h:125-138
+    bool haveFrameState = false;
+    float prevVP[16];
+    DevFrame *dFrame = nullptr;
+    unsigned long long *dCounters = nullptr;
+    void *dStaging = nullptr;
+    size_t stagingBytes = 0;
+    RtWave *wave = nullptr;
+    // timing
+    bool timing = false;
+    std::vector<StageEvent> pending;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> freeEvents;
+    double stageMs[RT_MAX_STAGES] = {0};
+    uint64_t stageLaunches[RT_MAX_STAGES] = {0};
+    int timedFrames = 0;
+};
+
+static int fail(RtContext *c, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_createError = buf;
+    return code;
+}
+#define HIP_TRY(c, expr)                                                                                  \
+    do {                                                                                                  \
+        hipError_t e_ = (expr);                                                                           \
+        if (e_ != hipSuccess) return fail((c), RT_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+static const char *kStageNames[RT_MAX_STAGES] = {"mega",       "primary",    "trace_primary", "gen_direct", "trace_gi", "trace_shadow",
+                                                 "gen_gi",     "trace_gi_shadow", "combine",  "assemble",   "",         ""};
+
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+__global__ void k_untile(const void *src, void *dst, FrameGeom g, int channels, int toF32) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= g.W * g.H) return;
+    int x = i % g.W, y = i / g.W;
+    int s = slot_of_pixel(g, x, y);
+    const uint16_t *in = (const uint16_t *)src + (size_t)(s < 0 ? 0 : s) * channels;
+    for (int c = 0; c < channels; ++c) {
+        uint16_t h = (s < 0) ? (uint16_t)0 : in[c];
+        if (toF32) ((float *)dst)[(size_t)i * channels + c] = f16_bits_to_f32(h);
+        else ((uint16_t *)dst)[(size_t)i * channels + c] = h;
+    }
+}
+
+// Gathered blocks (rank-major, blockBytes each, tile-major inside) -> row-major frame of halfs.
+__global__ void k_assemble(const void *gathered, void *dst, FrameGeom g, int channels, size_t blockBytes) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= g.W * g.H) return;
+    int x = i % g.W, y = i / g.W;
+    int tx = x >> 4, ty = y >> 4;
+    int t = ty * g.tilesX + tx;
+    int owner = t % g.world, local = t / g.world;
+    int lx = x & 15, ly = y & 15;
+    int q = (lx >> 3) | ((ly >> 3) << 1);
+    size_t slot = (size_t)local * 256 + q * 64 + (ly & 7) * 8 + (lx & 7);
+    const uint16_t *in = (const uint16_t *)((const char *)gathered + (size_t)owner * blockBytes) + slot * channels;
+    uint16_t *out = (uint16_t *)dst + (size_t)i * channels;
+    for (int c = 0; c < channels; ++c) out[c] = in[c];
+}
+
+__global__ void k_debug_eval(int op, const float *a, const float *b, const float *c, uint32_t *out, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float x = a[i], y = b ? b[i] : 0.0f, z = c ? c[i] : 0.0f;
+    float s, co;
+    uint32_t r = 0;
+    switch (op) {
+        case 0: sincosr(x, s, co); r = f2u(s); break;
+        case 1: sincosr(x, s, co); r = f2u(co); break;
+        case 2: r = f2u(exp2r(x)); break;
+        case 3: r = f2u(log2r(x)); break;
+        case 4: r = f2u(powr(x, y)); break;
+        case 5: r = f32_to_f16_bits(x); break;
+        case 6: r = rand_bits(x, y, (int)z); break;
+        case 7: r = f2u(x / y); break;
+        case 8: r = f2u(__builtin_sqrtf(x)); break;
+        case 9: r = f2u(1.0f / __builtin_sqrtf(x)); break;
+        default: break;
+    }
+    out[i] = r;
+}
+
+__global__ __launch_bounds__(256) void k_debug_trace(DevScene sc, int kind, const float *o, const float *d, const float *tMax, float eps,
+                                                     float inf, float *out7, int n) {
+    __shared__ StackEntry stack[4 * 32 * 64];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    StackEntry *stk = &stack[(threadIdx.x >> 6) * 32 * 64 + (threadIdx.x & 63)];
+    if (i >= n) return;
+    Work w;
+    work_zero(w);
+    V3 ro = ld3(o + (size_t)i * 3), rd = ld3(d + (size_t)i * 3);
+    float *out = out7 + (size_t)i * 7;
+    if (kind == 0) {
+        float t;
+        int tri;
+        bool hit = bvh_closest<false>(sc, ro, rd, eps, inf, stk, t, tri, w);
+        out[0] = hit ? t : inf;
+        if (hit) {
+            V3 p = ro + rd * t, nn = tri_normal(sc, tri);
+            out[1] = p.x; out[2] = p.y; out[3] = p.z; out[4] = nn.x; out[5] = nn.y; out[6] = nn.z;
+        } else {
+            for (int k = 1; k < 7; ++k) out[k] = 0.0f;
+        }
+    } else {
+        out[0] = bvh_anyhit<false>(sc, ro, rd, eps, tMax[i], stk, w) ? 1.0f : 0.0f;
+        for (int k = 1; k < 7; ++k) out[k] = 0.0f;
+    }
+}
+
+DevScene make_dev_scene(const RtContext *c) {
+    DevScene s;
+    s.wnodes = c->dWNodes;
+    s.tris = c->dTris;
+    s.env = c->dEnv;
+    s.envSize = c->envSize;
+    s.rootRef = c->rootRef;
+    s.hasBVH = (c->nNodes > 0 && c->nTris > 0) ? 1 : 0;
+    std::memcpy(s.rootMin, c->rootMin, 12);
+    std::memcpy(s.rootMax, c->rootMax, 12);
+    return s;
+}
+
+void free_targets(RtContext *c) {
+    for (int i = 0; i < 2; ++i) { if (c->dColor[i]) (void)hipFree(c->dColor[i]); c->dColor[i] = nullptr; }
+    if (c->dMotion) (void)hipFree(c->dMotion);
+    if (c->dGPos) (void)hipFree(c->dGPos);
+    if (c->dGNrm) (void)hipFree(c->dGNrm);
+    c->dMotion = nullptr; c->dGPos = c->dGNrm = nullptr;
+    c->sized = false;
+}
+
+int ensure_staging(RtContext *c, size_t bytes) {
+    if (c->stagingBytes >= bytes) return RT_OK;
+    if (c->dStaging) (void)hipFree(c->dStaging);
+    c->dStaging = nullptr; c->stagingBytes = 0;
+    HIP_TRY(c, hipMalloc(&c->dStaging, bytes));
+    c->stagingBytes = bytes;
+    return RT_OK;
+}
+
+void *target_ptr(RtContext *c, int which, int &channels) {
+    switch (which) {
+        case RT_TARGET_COLOR: channels = 4; return c->dColor[1 - c->writeIdx];   // last frame written = current read ping
+        case RT_TARGET_MOTION: channels = 2; return c->dMotion;
+        case RT_TARGET_GPOS: channels = 4; return c->dGPos;
+        case RT_TARGET_GNRM: channels = 4; return c->dGNrm;
+        default: channels = 0; return nullptr;
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// stage timing helpers (used by rt_wave.hip through RtStageTimer)
+void rt_stage_begin(RtContext *c, int stage) {
+    if (!c->timing) return;
+    StageEvent ev;
+    ev.stage = stage;
+    if (!c->freeEvents.empty()) { ev.a = c->freeEvents.back().first; ev.b = c->freeEvents.back().second; c->freeEvents.pop_back(); }
+    else { (void)hipEventCreate(&ev.a); (void)hipEventCreate(&ev.b); }
+    (void)hipEventRecord(ev.a, c->stream);
+    c->pending.push_back(ev);
+}
+void rt_stage_end(RtContext *c, int stage, int launches) {
+    if (!c->timing) return;
+    for (size_t i = c->pending.size(); i-- > 0;)
+        if (c->pending[i].stage == stage) { (void)hipEventRecord(c->pending[i].b, c->stream); break; }
+    c->stageLaunches[stage] += (uint64_t)launches;
+}
+static void resolve_stage_events(RtContext *c) {
+    (void)hipStreamSynchronize(c->stream);
+    for (auto &ev : c->pending) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, ev.a, ev.b) == hipSuccess) c->stageMs[ev.stage] += ms;
+        c->freeEvents.emplace_back(ev.a, ev.b);
+    }
+    c->pending.clear();
+}
+
+extern "C" {
+
+const char *rt_stage_name(int stage) { return (stage >= 0 && stage < RT_MAX_STAGES) ? kStageNames[stage] : ""; }
+
+const char *rt_last_error(const RtContext *ctx) { return ctx ? ctx->err.c_str() : g_createError.c_str(); }
+
+int rt_create(const RtDeviceConfig *cfg, RtContext **out) {
+    if (!cfg || !out) return fail(nullptr, RT_ERR_INVALID, "rt_create: null argument");
+    *out = nullptr;
+    if (cfg->worldSize < 1 || cfg->rank < 0 || cfg->rank >= cfg->worldSize) return fail(nullptr, RT_ERR_INVALID, "rt_create: bad rank/worldSize");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, RT_ERR_NO_DEVICE, "rt_create: no HIP device (%s); this library has no CPU path", hipGetErrorString(e));
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, RT_ERR_INVALID, "rt_create: device %d of %d", cfg->device, ndev);
+    e = hipSetDevice(cfg->device);
+    if (e != hipSuccess) return fail(nullptr, RT_ERR_NO_DEVICE, "hipSetDevice: %s", hipGetErrorString(e));
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, cfg->device);
+    if (e != hipSuccess) return fail(nullptr, RT_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, RT_ERR_UNSUPPORTED, "rt_create: device is %s, this library carries gfx950 code only", prop.gcnArchName);
+    RtContext *c = new RtContext();
+    c->cfg = *cfg;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipMalloc(&c->dFrame, sizeof(DevFrame)) != hipSuccess ||
+        hipMalloc(&c->dCounters, 8 * sizeof(unsigned long long)) != hipSuccess) {
+        delete c;
+        return fail(nullptr, RT_ERR_HIP, "rt_create: stream/alloc failed");
+    }
+    (void)hipMemset(c->dCounters, 0, 8 * sizeof(unsigned long long));
+    c->wave = rt_wave_create(prop.multiProcessorCount);
+    int rc = rt_upload_env(c, nullptr, 0, 0);   // dummy cube map like Application::initState (application.cpp:281)
+    if (rc != RT_OK) { g_createError = c->err; rt_destroy(c); return rc; }
+    *out = c;
+    return RT_OK;
+}
+
+void rt_destroy(RtContext *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->cfg.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    free_targets(c);
+    if (c->wave) rt_wave_destroy(c->wave);
+    if (c->dWNodes) (void)hipFree(c->dWNodes);
+    if (c->dTris) (void)hipFree(c->dTris);
+    if (c->dEnv) (void)hipFree(c->dEnv);
+    if (c->dFrame) (void)hipFree(c->dFrame);
+    if (c->dCounters) (void)hipFree(c->dCounters);
+    if (c->dStaging) (void)hipFree(c->dStaging);
+    for (auto &ev : c->pending) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+    for (auto &p : c->freeEvents) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int rt_upload_bvh(RtContext *c, const float *nodes12, int nNodes, const float *tris12, int nTris) {
+    if (!c) return RT_ERR_INVALID;
+    if (nNodes < 0 || nTris < 0 || (nNodes > 0 && !nodes12) || (nTris > 0 && !tris12)) return fail(c, RT_ERR_INVALID, "rt_upload_bvh: bad arguments");
+    (void)hipSetDevice(c->cfg.device);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->dWNodes) (void)hipFree(c->dWNodes);
+    if (c->dTris) (void)hipFree(c->dTris);
+    c->dWNodes = c->dTris = nullptr;
+    c->nNodes = c->nTris = c->nInner = 0;
+    c->treeDepth = 0;
+    if (nNodes == 0 || nTris == 0) return RT_OK;
+    if (nTris >= (1 << 28)) return fail(c, RT_ERR_UNSUPPORTED, "rt_upload_bvh: %d triangles exceed the 2^28 leaf encoding", nTris);
+
+    // Decode the reference's float-encoded links exactly as nodeFetch does (rt_bvh.glsl:97-100).
+    struct N { int left, right, first, count; };
+    std::vector<N> nd((size_t)nNodes);
+    std::vector<int> innerIdx((size_t)nNodes, -1);
+    int nInner = 0;
+    for (int i = 0; i < nNodes; ++i) {
+        const float *p = nodes12 + (size_t)i * 12;
+        nd[(size_t)i] = {(int)(p[3] + 0.5f), (int)(p[7] + 0.5f), (int)(p[8] + 0.5f), (int)(p[9] + 0.5f)};
+        const N &n = nd[(size_t)i];
+        if (n.count > 0) {
+            if (n.count > 8 || n.first < 0 || n.first + n.count > nTris)
+                return fail(c, RT_ERR_UNSUPPORTED, "rt_upload_bvh: leaf %d has first=%d count=%d (leaves hold 1..8 triangles)", i, n.first, n.count);
+        } else {
+            if (n.left <= 0 || n.right <= 0 || n.left >= nNodes || n.right >= nNodes)
+                return fail(c, RT_ERR_INVALID, "rt_upload_bvh: inner node %d has children %d,%d", i, n.left, n.right);
+            innerIdx[(size_t)i] = nInner++;
+        }
+    }
+    auto refOf = [&](int node) {
+        const N &n = nd[(size_t)node];
+        return (n.count > 0) ? -(((n.first << 3) | (n.count - 1)) + 1) : innerIdx[(size_t)node];
+    };
+    std::vector<float> wn((size_t)std::max(nInner, 1) * 16, 0.0f);
+    for (int i = 0; i < nNodes; ++i) {
+        if (innerIdx[(size_t)i] < 0) continue;
+        const float *L = nodes12 + (size_t)nd[(size_t)i].left * 12, *R = nodes12 + (size_t)nd[(size_t)i].right * 12;
+        float *o = &wn[(size_t)innerIdx[(size_t)i] * 16];
+        int rl = refOf(nd[(size_t)i].left), rr = refOf(nd[(size_t)i].right);
+        o[0] = L[0]; o[1] = L[1]; o[2] = L[2]; std::memcpy(&o[3], &rl, 4);
+        o[4] = L[4]; o[5] = L[5]; o[6] = L[6]; std::memcpy(&o[7], &rr, 4);
+        o[8] = R[0]; o[9] = R[1]; o[10] = R[2];
+        o[12] = R[4]; o[13] = R[5]; o[14] = R[6];
+    }
+    // depth of the tree (iterative), bounds the traversal stack: one deferred sibling per level
+    int depth = 0;
+    {
+        std::vector<std::pair<int, int>> st{{0, 1}};
+        size_t visited = 0;
+        while (!st.empty()) {
+            auto [n, d] = st.back();
+            st.pop_back();
+            if (++visited > (size_t)nNodes) return fail(c, RT_ERR_INVALID, "rt_upload_bvh: node links form a cycle");
+            depth = std::max(depth, d);
+            if (nd[(size_t)n].count <= 0) { st.push_back({nd[(size_t)n].left, d + 1}); st.push_back({nd[(size_t)n].right, d + 1}); }
+        }
+    }
+    if (depth > 32) return fail(c, RT_ERR_UNSUPPORTED, "rt_upload_bvh: tree depth %d exceeds the 32-entry traversal stack", depth);
+    HIP_TRY(c, hipMalloc(&c->dWNodes, wn.size() * sizeof(float)));
+    HIP_TRY(c, hipMalloc(&c->dTris, (size_t)nTris * 12 * sizeof(float)));
+    HIP_TRY(c, hipMemcpy(c->dWNodes, wn.data(), wn.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->dTris, tris12, (size_t)nTris * 12 * sizeof(float), hipMemcpyHostToDevice));
+    c->nNodes = nNodes; c->nTris = nTris; c->nInner = nInner; c->treeDepth = depth;
+    c->rootRef = refOf(0);
+    std::memcpy(c->rootMin, nodes12, 12);
+    std::memcpy(c->rootMax, nodes12 + 4, 12);
+    return RT_OK;
+}
+
+int rt_upload_env(RtContext *c, const uint8_t *faces, int faceSize, int channels) {
+    if (!c) return RT_ERR_INVALID;
+    (void)hipSetDevice(c->cfg.device);
+    static const uint8_t dummy[6 * 4] = {128, 128, 255, 255, 128, 128, 255, 255, 128, 128, 255, 255,
+                                         128, 128, 255, 255, 128, 128, 255, 255, 128, 128, 255, 255};   // cubemap.cpp:13
+    if (!faces) { faces = dummy; faceSize = 1; channels = 4; }
+    if (faceSize <= 0 || (channels != 3 && channels != 4)) return fail(c, RT_ERR_INVALID, "rt_upload_env: faceSize=%d channels=%d", faceSize, channels);
+    const size_t texels = (size_t)6 * faceSize * faceSize;
+    std::vector<uint8_t> rgba(texels * 4);
+    for (size_t i = 0; i < texels; ++i) {
+        rgba[i * 4 + 0] = faces[i * channels + 0];
+        rgba[i * 4 + 1] = faces[i * channels + 1];
+        rgba[i * 4 + 2] = faces[i * channels + 2];
+        rgba[i * 4 + 3] = (channels == 4) ? faces[i * channels + 3] : (uint8_t)255;
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->dEnv) (void)hipFree(c->dEnv);
+    c->dEnv = nullptr;
+    HIP_TRY(c, hipMalloc(&c->dEnv, texels * 4));
+    HIP_TRY(c, hipMemcpy(c->dEnv, rgba.data(), texels * 4, hipMemcpyHostToDevice));
+    c->envSize = faceSize;
+    return RT_OK;
+}
+
+int rt_resize(RtContext *c, int w, int h) {
+    if (!c) return RT_ERR_INVALID;
+    if (w <= 0 || h <= 0) return fail(c, RT_ERR_INVALID, "rt_resize: %dx%d", w, h);
+    (void)hipSetDevice(c->cfg.device);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    free_targets(c);
+    FrameGeom g;
+    g.W = w; g.H = h;
+    g.tilesX = (w + RT_TILE_DIM - 1) / RT_TILE_DIM;
+    g.tilesY = (h + RT_TILE_DIM - 1) / RT_TILE_DIM;
+    g.nTiles = g.tilesX * g.tilesY;
+    g.rank = c->cfg.rank; g.world = c->cfg.worldSize;
+    g.nLocalTiles = (g.nTiles - g.rank + g.world - 1) / g.world;
+    if (g.nLocalTiles < 0) g.nLocalTiles = 0;
+    c->g = g;
+    // every rank allocates the padded size so gather blocks are equal
+    const size_t maxLocal = (size_t)(g.nTiles + g.world - 1) / g.world;
+    c->nSlots = std::max<size_t>(maxLocal, 1) * RT_TILE_PIXELS;
+    for (int i = 0; i < 2; ++i) HIP_TRY(c, hipMalloc(&c->dColor[i], c->nSlots * 8));
+    HIP_TRY(c, hipMalloc(&c->dMotion, c->nSlots * 4));
+    HIP_TRY(c, hipMalloc(&c->dGPos, c->nSlots * 8));
+    HIP_TRY(c, hipMalloc(&c->dGNrm, c->nSlots * 8));
+    c->sized = true;
+    c->haveFrameState = false;
+    return rt_reset_accum(c);
+}
+
+int rt_reset_accum(RtContext *c) {
+    if (!c) return RT_ERR_INVALID;
+    if (!c->sized) return fail(c, RT_ERR_STATE, "rt_reset_accum before rt_resize");
+    (void)hipSetDevice(c->cfg.device);
+    c->frameIndex = 0;
+    c->writeIdx = 0;
+    for (int i = 0; i < 2; ++i) HIP_TRY(c, hipMemsetAsync(c->dColor[i], 0, c->nSlots * 8, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->dMotion, 0, c->nSlots * 4, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->dGPos, 0, c->nSlots * 8, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->dGNrm, 0, c->nSlots * 8, c->stream));
+    return RT_OK;
+}
+
+int rt_frame_index(const RtContext *c) { return c ? c->frameIndex : RT_ERR_INVALID; }
+
+int rt_render_frame(RtContext *c, const RtUniforms *uIn) {
+    if (!c || !uIn) return RT_ERR_INVALID;
+    if (!c->sized) return fail(c, RT_ERR_STATE, "rt_render_frame before rt_resize");
+    (void)hipSetDevice(c->cfg.device);
+    DevFrame fr;
+    fr.u = *uIn;
+    fr.u.frameIndex = c->frameIndex;
+    if ((int)fr.u.resolution[0] != c->g.W || (int)fr.u.resolution[1] != c->g.H)
+        return fail(c, RT_ERR_INVALID, "rt_render_frame: uResolution %gx%g != framebuffer %dx%d", fr.u.resolution[0], fr.u.resolution[1], c->g.W, c->g.H);
+    if (fr.u.useBVH == 1 && fr.u.nodeCount > 0 && fr.u.triCount > 0 && (c->nNodes == 0 || fr.u.nodeCount > c->nNodes || fr.u.triCount > c->nTris))
+        return fail(c, RT_ERR_STATE, "rt_render_frame: uniforms name %d nodes / %d tris, uploaded %d / %d", fr.u.nodeCount, fr.u.triCount, c->nNodes, c->nTris);
+    if (fr.u.useEnvMap == 1 && !c->dEnv) return fail(c, RT_ERR_STATE, "rt_render_frame: uUseEnvMap without an environment");
+    if (fr.u.cameraMoved == 1 && c->g.world > 1)
+        return fail(c, RT_ERR_UNSUPPORTED, "rt_render_frame: moving-camera reprojection reads other ranks' history; needs the history all-gather (not in this build)");
+    fr.sc = make_dev_scene(c);
+    if (!(fr.u.nodeCount > 0 && fr.u.triCount > 0)) fr.sc.hasBVH = 0;
+    fr.g = c->g;
+    HIP_TRY(c, hipMemcpyAsync(c->dFrame, &fr, sizeof(fr), hipMemcpyHostToDevice, c->stream));
+    Targets tg;
+    tg.color = c->dColor[c->writeIdx];
+    tg.prev = c->dColor[1 - c->writeIdx];
+    tg.motion = c->dMotion; tg.gpos = c->dGPos; tg.gnrm = c->dGNrm;
+    const bool count = c->cfg.countWork != 0;
+    int pipeline = c->cfg.pipeline;
+    if (pipeline == RT_PIPELINE_AUTO) pipeline = RT_PIPELINE_MEGAKERNEL;  // TODO wavefront
+    if (pipeline == RT_PIPELINE_WAVEFRONT && !(fr.u.useBVH == 1)) pipeline = RT_PIPELINE_MEGAKERNEL;   // analytic scene: pure ALU, megakernel only
+    if (pipeline == RT_PIPELINE_WAVEFRONT) {
+        int rc = rt_wave_render(c->wave, c, c->stream, c->dFrame, fr, tg, c->dCounters, count, std::max(c->treeDepth, 1));
+        if (rc != RT_OK) return fail(c, rc, "wavefront pipeline: %s", rt_wave_error(c->wave));
+    } else {
+        rt_stage_begin(c, 0);
+        HIP_TRY(c, rtl::launch_mega(c->stream, c->dFrame, tg, c->dCounters, count, std::max(c->treeDepth, 1), c->g.nLocalTiles));
+        rt_stage_end(c, 0, 1);
+    }
+    if (c->timing) c->timedFrames++;
+    c->frameIndex++;                 // Accum::swapAfterFrame, include/render/accum.h:125-128
+    c->writeIdx = 1 - c->writeIdx;
+    return RT_OK;
+}
+
+int rt_render_ray(RtContext *c, const RtRenderParams *params, const RtCamera *cam, int useBVH, int showMotion, const float *currView,
+                  const float *currProj) {
+    if (!c || !params || !cam) return RT_ERR_INVALID;
+    if (!c->sized) return fail(c, RT_ERR_STATE, "rt_render_ray before rt_resize");
+    float V[16], P[16], VP[16];
+    if (currView) std::memcpy(V, currView, 64); else rt_camera_view(cam, V);
+    if (currProj) std::memcpy(P, currProj, 64); else rt_camera_proj(cam, P);
+    rt_mat4_mul(P, V, VP);                                   // FrameState::beginFrame, frame_state.h:68-73
+    if (!c->haveFrameState) { std::memcpy(c->prevVP, VP, 64); c->haveFrameState = true; }   // application.cpp:316-319
+    const int moved = rt_camera_moved(VP, c->prevVP);        // application.cpp:387-395
+    RtUniforms u;
+    rt_make_uniforms(params, cam, V, VP, c->prevVP, c->g.W, c->g.H, c->frameIndex, moved, useBVH, showMotion, c->nNodes, c->nTris,
+                     c->dEnv != nullptr, &u);
+    int rc = rt_render_frame(c, &u);
+    if (rc != RT_OK) return rc;
+    std::memcpy(c->prevVP, VP, 64);                          // FrameState::endFrame, frame_state.h:81-84
+    return RT_OK;
+}
+
+int rt_synchronize(RtContext *c) {
+    if (!c) return RT_ERR_INVALID;
+    (void)hipSetDevice(c->cfg.device);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+int rt_read_target(RtContext *c, int which, void *dst, int fmt) {
+    if (!c || !dst) return RT_ERR_INVALID;
+    if (!c->sized) return fail(c, RT_ERR_STATE, "rt_read_target before rt_resize");
+    (void)hipSetDevice(c->cfg.device);
+    int ch;
+    void *src = target_ptr(c, which, ch);
+    if (!src || (fmt != RT_FORMAT_F16 && fmt != RT_FORMAT_F32)) return fail(c, RT_ERR_INVALID, "rt_read_target: which=%d format=%d", which, fmt);
+    const size_t n = (size_t)c->g.W * c->g.H, bytes = n * ch * (fmt == RT_FORMAT_F32 ? 4 : 2);
+    int rc = ensure_staging(c, bytes);
+    if (rc != RT_OK) return rc;
+    hipLaunchKernelGGL(k_untile, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, src, c->dStaging, c->g, ch, fmt == RT_FORMAT_F32 ? 1 : 0);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(dst, c->dStaging, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+int rt_local_target(RtContext *c, int which, void **devPtr, size_t *bytes) {
+    if (!c || !devPtr || !bytes) return RT_ERR_INVALID;
+    if (!c->sized) return fail(c, RT_ERR_STATE, "rt_local_target before rt_resize");
+    int ch;
+    void *p = target_ptr(c, which, ch);
+    if (!p) return fail(c, RT_ERR_INVALID, "rt_local_target: which=%d", which);
+    *devPtr = p;
+    *bytes = c->nSlots * ch * 2;
+    return RT_OK;
+}
+int rt_gather_block_bytes(const RtContext *c, int which, size_t *bytes) {
+    if (!c || !bytes || !c->sized) return RT_ERR_INVALID;
+    const int ch = (which == RT_TARGET_MOTION) ? 2 : 4;
+    *bytes = c->nSlots * ch * 2;
+    return RT_OK;
+}
+int rt_assemble_gathered(RtContext *c, int which, const void *gatheredDev, void *dstDev) {
+    if (!c || !gatheredDev || !dstDev) return RT_ERR_INVALID;
+    if (!c->sized) return fail(c, RT_ERR_STATE, "rt_assemble_gathered before rt_resize");
+    (void)hipSetDevice(c->cfg.device);
+    const int ch = (which == RT_TARGET_MOTION) ? 2 : 4;
+    const size_t n = (size_t)c->g.W * c->g.H;
+    rt_stage_begin(c, 9);
+    hipLaunchKernelGGL(k_assemble, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, gatheredDev, dstDev, c->g, ch, c->nSlots * ch * 2);
+    rt_stage_end(c, 9, 1);
+    HIP_TRY(c, hipGetLastError());
+    return RT_OK;
+}
+int rt_stream(RtContext *c, void **s) {
+    if (!c || !s) return RT_ERR_INVALID;
+    *s = (void *)c->stream;
+    return RT_OK;
+}
+
+int rt_get_counters(RtContext *c, RtCounters *out) {
+    if (!c || !out) return RT_ERR_INVALID;
+    if (!c->cfg.countWork) return fail(c, RT_ERR_STATE, "rt_get_counters: context created without countWork");
+    (void)hipSetDevice(c->cfg.device);
+    unsigned long long v[8];
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(v, c->dCounters, sizeof v, hipMemcpyDeviceToHost));
+    out->raysClosest = v[0]; out->raysShadow = v[1]; out->raysAnalytic = v[2]; out->nodeFetch = v[3];
+    out->triFetch = v[4]; out->envLookup = v[5]; out->hitPixels = v[6];
+    return RT_OK;
+}
+int rt_reset_counters(RtContext *c) {
+    if (!c) return RT_ERR_INVALID;
+    (void)hipSetDevice(c->cfg.device);
+    HIP_TRY(c, hipMemsetAsync(c->dCounters, 0, 8 * sizeof(unsigned long long), c->stream));
+    return RT_OK;
+}
+
+int rt_enable_stage_timing(RtContext *c, int enable) {
+    if (!c) return RT_ERR_INVALID;
+    (void)hipSetDevice(c->cfg.device);
+    resolve_stage_events(c);
+    c->timing = enable != 0;
+    std::memset(c->stageMs, 0, sizeof c->stageMs);
+    std::memset(c->stageLaunches, 0, sizeof c->stageLaunches);
+    c->timedFrames = 0;
+    return RT_OK;
+}
+int rt_get_stage_times(RtContext *c, RtStageTimes *out) {
+    if (!c || !out) return RT_ERR_INVALID;
+    (void)hipSetDevice(c->cfg.device);
+    resolve_stage_events(c);
+    out->nStages = 10;
+    out->frames = c->timedFrames;
+    for (int i = 0; i < RT_MAX_STAGES; ++i) { out->ms[i] = c->stageMs[i]; out->launches[i] = c->stageLaunches[i]; }
+    return RT_OK;
+}
+
+int rt_debug_eval(RtContext *c, int op, const float *a, const float *b, const float *cc, uint32_t *out, int n) {
+    if (!c || !a || !out || n <= 0) return RT_ERR_INVALID;
+    (void)hipSetDevice(c->cfg.device);
+    float *da = nullptr, *db = nullptr, *dc = nullptr;
+    uint32_t *dout = nullptr;
+    const size_t bytes = (size_t)n * 4;
+    HIP_TRY(c, hipMalloc(&da, bytes));
+    HIP_TRY(c, hipMalloc(&dout, bytes));
+    HIP_TRY(c, hipMemcpy(da, a, bytes, hipMemcpyHostToDevice));
+    if (b) { HIP_TRY(c, hipMalloc(&db, bytes)); HIP_TRY(c, hipMemcpy(db, b, bytes, hipMemcpyHostToDevice)); }
+    if (cc) { HIP_TRY(c, hipMalloc(&dc, bytes)); HIP_TRY(c, hipMemcpy(dc, cc, bytes, hipMemcpyHostToDevice)); }
+    hipLaunchKernelGGL(k_debug_eval, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, op, da, db, dc, dout, n);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost));
+    (void)hipFree(da); (void)hipFree(dout);
+    if (db) (void)hipFree(db);
+    if (dc) (void)hipFree(dc);
+    return RT_OK;
+}
+
+int rt_debug_trace(RtContext *c, int kind, const float *origins, const float *dirs, const float *tMax, float eps, float inf, float *out7, int n) {
+    if (!c || !origins || !dirs || !out7 || n <= 0 || (kind == 1 && !tMax)) return RT_ERR_INVALID;
+    (void)hipSetDevice(c->cfg.device);
+    float *dO = nullptr, *dD = nullptr, *dT = nullptr, *dOut = nullptr;
+    HIP_TRY(c, hipMalloc(&dO, (size_t)n * 12));
+    HIP_TRY(c, hipMalloc(&dD, (size_t)n * 12));
+    HIP_TRY(c, hipMalloc(&dT, (size_t)n * 4));
+    HIP_TRY(c, hipMalloc(&dOut, (size_t)n * 28));
+    HIP_TRY(c, hipMemcpy(dO, origins, (size_t)n * 12, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(dD, dirs, (size_t)n * 12, hipMemcpyHostToDevice));
+    if (tMax) HIP_TRY(c, hipMemcpy(dT, tMax, (size_t)n * 4, hipMemcpyHostToDevice));
+    DevScene sc = make_dev_scene(c);
+    hipLaunchKernelGGL(k_debug_trace, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, sc, kind, dO, dD, dT, eps, inf, dOut, n);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(out7, dOut, (size_t)n * 28, hipMemcpyDeviceToHost));
+    (void)hipFree(dO); (void)hipFree(dD); (void)hipFree(dT); (void)hipFree(dOut);
+    return RT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,99 @@
+// rt_frame.hpp -- device-resident frame description shared by all kernels, the framebuffer tile
+// layout, and the launcher prototypes that connect rt_api.hip to the kernel translation units.
+//
+// Framebuffer layout in HBM ("tile-major"): the W x H frame is cut into 16x16-pixel tiles,
+// globalTile = tileY * tilesX + tileX.  Rank r of a world of n owns the tiles with
+// globalTile % n == r and stores them densely: localTile = globalTile / n.  A tile is 256
+// consecutive pixels = one 256-thread workgroup; inside it each 64-pixel run is one 8x8 block =
+// one wavefront, so a wave's loads/stores of a target are one contiguous 512-byte (RGBA16F) run
+// and its rays start out spatially coherent.
+//   pixel slot = localTile * 256 + q * 64 + lane,   q = 8x8 quadrant (bit0: x half, bit1: y half),
+//   x = tileX*16 + (q&1)*8 + (lane&7),  y = tileY*16 + (q>>1)*8 + (lane>>3)      (y = 0 is the bottom row)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "rt_device_shade.hpp"
+
+namespace rtd {
+
+struct FrameGeom {
+    int W, H, tilesX, tilesY, nTiles, rank, world, nLocalTiles;
+};
+
+struct DevFrame {   // one copy in HBM, refreshed per frame; kernels read it through scalar loads
+    RtUniforms u;
+    DevScene sc;
+    FrameGeom g;
+};
+
+struct Targets {
+    uint2 *color;        // COLOR0 write ping  (RGBA16F: rgb + luma second moment), rt.frag:29
+    const uint2 *prev;   // COLOR0 read pong   (uPrevAccum)
+    uint32_t *motion;    // COLOR1 RG16F
+    uint2 *gpos;         // COLOR2 RGBA16F
+    uint2 *gnrm;         // COLOR3 RGBA16F
+};
+
+RT_DEV bool pixel_of_slot(const FrameGeom &g, int localTile, int tid, int &x, int &y) {
+    int t = localTile * g.world + g.rank;
+    int tx = t % g.tilesX, ty = t / g.tilesX;
+    int q = tid >> 6, lane = tid & 63;
+    x = tx * 16 + (q & 1) * 8 + (lane & 7);
+    y = ty * 16 + (q >> 1) * 8 + (lane >> 3);
+    return t < g.nTiles && x < g.W && y < g.H;
+}
+// slot of pixel (x,y) if this rank owns it, else -1
+RT_DEV int slot_of_pixel(const FrameGeom &g, int x, int y) {
+    int tx = x >> 4, ty = y >> 4;
+    int t = ty * g.tilesX + tx;
+    if (t % g.world != g.rank) return -1;
+    int lx = x & 15, ly = y & 15;
+    int q = (lx >> 3) | ((ly >> 3) << 1);
+    return (t / g.world) * 256 + q * 64 + (ly & 7) * 8 + (lx & 7);
+}
+
+RT_DEV uint2 pack_half4(V4 v) {
+    uint2 r;
+    r.x = (uint32_t)f32_to_f16_bits(v.x) | ((uint32_t)f32_to_f16_bits(v.y) << 16);
+    r.y = (uint32_t)f32_to_f16_bits(v.z) | ((uint32_t)f32_to_f16_bits(v.w) << 16);
+    return r;
+}
+RT_DEV uint32_t pack_half2(V2 v) { return (uint32_t)f32_to_f16_bits(v.x) | ((uint32_t)f32_to_f16_bits(v.y) << 16); }
+RT_DEV V4 unpack_half4(uint2 r) {
+    return mk4(f16_bits_to_f32((uint16_t)(r.x & 0xffffu)), f16_bits_to_f32((uint16_t)(r.x >> 16)),
+               f16_bits_to_f32((uint16_t)(r.y & 0xffffu)), f16_bits_to_f32((uint16_t)(r.y >> 16)));
+}
+
+// History access for resolveTAA (rt_taa.glsl:87,128): NEAREST, CLAMP_TO_EDGE.
+struct HistoryTex {
+    const uint2 *prev;
+    const FrameGeom *g;
+    int slot;
+    RT_DEV V4 own() const { return unpack_half4(prev[slot]); }
+    RT_DEV V4 at(float u, float v) const {
+        int x = (int)__builtin_floorf(u * (float)g->W), y = (int)__builtin_floorf(v * (float)g->H);
+        x = min(max(x, 0), g->W - 1);
+        y = min(max(y, 0), g->H - 1);
+        int s = slot_of_pixel(*g, x, y);
+        return unpack_half4(prev[s < 0 ? slot : s]);   // s < 0 only with world > 1, which the host rejects for moving cameras
+    }
+};
+
+// Block-wide accumulation of per-lane work counters into the 7 global 64-bit counters.
+RT_DEV void flush_work(const Work &w, unsigned long long *counters) {
+    const uint32_t v[7] = {w.raysClosest, w.raysShadow, w.raysAnalytic, w.nodeFetch, w.triFetch, w.envLookup, w.hitPixels};
+    for (int i = 0; i < 7; ++i) {
+        unsigned long long s = v[i];
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        if ((threadIdx.x & 63) == 0 && s) atomicAdd(&counters[i], s);
+    }
+}
+
+}  // namespace rtd
+
+// ---- launchers implemented in the kernel translation units --------------------------------------
+struct RtWaveBuffers;   // rt_wave.hip
+namespace rtl {
+hipError_t launch_mega(hipStream_t s, const rtd::DevFrame *frame, rtd::Targets tg, unsigned long long *counters, bool count,
+                       int stackDepth, int nLocalTiles);
+}
