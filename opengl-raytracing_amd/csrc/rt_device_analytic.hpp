@@ -111,6 +111,7 @@ __device__ __noinline__ V3 directLightA(const Frag &F, const Hit &h, int frame, 
     // sunDirect
     V3 sun = mk3(0.0f);
     if (u.sunEnabled != 0) {
+        V3 Vs = normalize(V);   // sunDirect re-normalises the already normalised V (rt_lighting.glsl:119)
         V3 L = normalize(-ld3(u.sunDir));
         float ndl = fmaxr(dot(N, L), 0.0f);
         if (ndl > 0.0f) {
@@ -120,7 +121,7 @@ __device__ __noinline__ V3 directLightA(const Frag &F, const Hit &h, int frame, 
             bool blocked = traceAnalyticCore<COUNT>(u, origin, L, true, true, tmp, w);
             if (!blocked) {
                 float specStrength = (mat.type == 0) ? mat.specStrength : 0.0f;
-                sun = shadeLambertPhong(u.pi, N, V, L, ld3(u.sunColor) * u.sunIntensity, mat.albedo, specStrength, mat.gloss);
+                sun = shadeLambertPhong(u.pi, N, Vs, L, ld3(u.sunColor) * u.sunIntensity, mat.albedo, specStrength, mat.gloss);
             }
         }
     }
@@ -129,6 +130,7 @@ __device__ __noinline__ V3 directLightA(const Frag &F, const Hit &h, int frame, 
     // pointDirect
     V3 pt = mk3(0.0f);
     if (u.pointLightEnabled != 0) {
+        V3 Vp = normalize(V);   // pointDirect does the same (rt_lighting.glsl:186)
         V3 toL = ld3(u.pointLightPos) - h.p;
         float dist2 = dot(toL, toL);
         if (dist2 > 1e-6f) {
@@ -143,7 +145,7 @@ __device__ __noinline__ V3 directLightA(const Frag &F, const Hit &h, int frame, 
                 if (!blocked) {
                     V3 Li = ld3(u.pointLightColor) * (u.pointLightIntensity / fmaxr(dist2, 1e-4f));
                     float specStrength = (mat.type == 0) ? mat.specStrength : 0.0f;
-                    pt = shadeLambertPhong(u.pi, N, V, L, Li, mat.albedo, specStrength, mat.gloss);
+                    pt = shadeLambertPhong(u.pi, N, Vp, L, Li, mat.albedo, specStrength, mat.gloss);
                 }
             }
         }

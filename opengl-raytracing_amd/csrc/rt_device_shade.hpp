@@ -403,6 +403,7 @@ RT_DEV V3 directLightBVH(T &tr, const Frag &F, int seg, V3 hp, V3 hn, int frame,
     // sunDirect :114-144
     V3 sun = mk3(0.0f);
     if (u.sunEnabled != 0) {
+        V3 Vs = normalize(V);   // sunDirect re-normalises the already normalised V (rt_lighting.glsl:119)
         V3 L = normalize(-ld3(u.sunDir));
         float ndl = fmaxr(dot(N, L), 0.0f);
         if (ndl > 0.0f) {
@@ -410,7 +411,7 @@ RT_DEV V3 directLightBVH(T &tr, const Frag &F, int seg, V3 hp, V3 hn, int frame,
             float e = epsForDist(maxT);
             V3 origin = hp + N * e;
             bool blocked = tr.shadow(seg, 4, origin, L, maxT - e);
-            if (!blocked) sun = shadeLambertPhong(u.pi, N, V, L, ld3(u.sunColor) * u.sunIntensity, albedo, specStrength, gloss);
+            if (!blocked) sun = shadeLambertPhong(u.pi, N, Vs, L, ld3(u.sunColor) * u.sunIntensity, albedo, specStrength, gloss);
         }
     }
     sum = sum + sun;
@@ -418,6 +419,7 @@ RT_DEV V3 directLightBVH(T &tr, const Frag &F, int seg, V3 hp, V3 hn, int frame,
     // pointDirect :181-214
     V3 pt = mk3(0.0f);
     if (u.pointLightEnabled != 0) {
+        V3 Vp = normalize(V);   // pointDirect does the same (rt_lighting.glsl:186)
         V3 toL = ld3(u.pointLightPos) - hp;
         float dist2 = dot(toL, toL);
         if (dist2 > 1e-6f) {
@@ -430,7 +432,7 @@ RT_DEV V3 directLightBVH(T &tr, const Frag &F, int seg, V3 hp, V3 hn, int frame,
                 bool blocked = tr.shadow(seg, 5, origin, L, dist - e);
                 if (!blocked) {
                     V3 Li = ld3(u.pointLightColor) * (u.pointLightIntensity / fmaxr(dist2, 1e-4f));
-                    pt = shadeLambertPhong(u.pi, N, V, L, Li, albedo, specStrength, gloss);
+                    pt = shadeLambertPhong(u.pi, N, Vp, L, Li, albedo, specStrength, gloss);
                 }
             }
         }
