@@ -9,8 +9,8 @@ region.  Headline camera = the close-up of SURVEY.md 8d (mesh ~45 % of the frame
 reference's default camera (mesh < 1 % of the frame) is reported beside it in "default_camera".
 
 N > 1 (launched by torch.distributed.run, one process per GPU): the frame's 16x16 tiles are dealt
-round-robin to the ranks (weak... no: the frame is fixed, so this is STRONG scaling), every rank
-holds a BVH replica, and each frame ends with one RCCL gather of COLOR0 to rank 0 over xGMI plus
+round-robin to the ranks (the frame is fixed, so this is STRONG scaling), every rank holds a BVH
+replica, and each frame ends with one RCCL gather of COLOR0 to rank 0 over xGMI plus
 the un-tiling kernel.  value = rays of the whole frame / max-over-ranks time.
 
 A "ray" is one traceBVH / traceBVHShadow call of the reference's shader for this frame
@@ -38,6 +38,18 @@ W, H, SPP = 1920, 1080, 4
 def algorithmic_bytes(c, npix):
     """SURVEY.md 8d / BASELINE.md: reference-layout bytes of one frame."""
     return 48 * c.nodeFetch + 48 * c.triFetch + npix * 36 + 12 * c.envLookup
+
+
+def usable_cores():
+    """CPU threads this process may really use: affinity, capped by the cgroup CPU quota (the GPU box gives 16 of 256)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
 
 
 class _DevArray:
@@ -83,7 +95,9 @@ def main():
     npix = W * H
 
     def make_renderer(count):
-        r = rt.Renderer(device=local_rank, rank=rank, world_size=world, pipeline=pipeline, count_work=count)
+        # work counters (reference units) come from the reference-shaped megakernel; the timed run uses `pipeline`
+        r = rt.Renderer(device=local_rank, rank=rank, world_size=world,
+                        pipeline=rt.RT_PIPELINE_MEGAKERNEL if count else pipeline, count_work=count)
         r.upload_bvh(nodes, tris)
         r.upload_env(faces)
         r.resize(W, H)
@@ -198,21 +212,24 @@ def main():
 
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         import oracle as orc
-        cores = os.cpu_count() or 1
+        cores = usable_cores()
         cam = scenes.camera("closeup")
         u = uniforms(cam, args.warmup)
-        # calibrate on 4 rows through the middle of the mesh, then take as many rows as fit the budget
-        t0 = time.perf_counter()
-        _, c0 = orc.render(u, nodes, tris, faces, None, region=(0, H // 2, W, H // 2 + 4), nthreads=cores)
-        cal = time.perf_counter() - t0
-        rows = int(max(4, min(H, 4 * args.cpu_seconds / max(cal, 1e-3))))
-        y0 = max(0, H // 2 - rows // 2)
-        t0 = time.perf_counter()
-        _, c1 = orc.render(u, nodes, tris, faces, None, region=(0, y0, W, y0 + rows), nthreads=cores)
-        dt = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": c1.rays / dt / 1e6, "unit": "Mray/s", "cores": cores, "kind": "port",
-                               "sample": f"oracle (scalar fp32 C++ restatement, -O2), rows {y0}..{y0 + rows} of the same 1080p/4spp "
-                                         f"close-up frame {args.warmup}, {c1.rays} rays in {dt:.1f} s on {cores} threads"}
+        # bands of 16 rows outward from the middle of the frame until the time budget is used
+        order = sorted(range(0, H, 16), key=lambda y: abs(y + 8 - H // 2))
+        rays_cpu, dt, bands = 0, 0.0, 0
+        for y in order:
+            t0 = time.perf_counter()
+            _, c1 = orc.render(u, nodes, tris, faces, None, region=(0, y, W, min(y + 16, H)), nthreads=cores)
+            dt += time.perf_counter() - t0
+            rays_cpu += c1.rays
+            bands += 1
+            if dt >= args.cpu_seconds:
+                break
+        out["cpu_baseline"] = {"value": rays_cpu / dt / 1e6, "unit": "Mray/s", "cores": cores, "kind": "port",
+                               "sample": f"oracle (scalar fp32 C++ restatement of shaders/rt, g++ -O2), {bands} 16-row bands around the "
+                                         f"middle of the same 1080p/4spp close-up frame {args.warmup}: {rays_cpu} rays in {dt:.1f} s "
+                                         f"on {cores} threads"}
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

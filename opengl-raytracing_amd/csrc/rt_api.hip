@@ -70,8 +70,8 @@ static int fail(RtContext *c, int code, const char *fmt, ...) {
         if (e_ != hipSuccess) return fail((c), RT_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
-static const char *kStageNames[RT_MAX_STAGES] = {"mega",       "primary",    "trace_primary", "gen_direct", "trace_gi", "trace_shadow",
-                                                 "gen_gi",     "trace_gi_shadow", "combine",  "assemble",   "",         ""};
+static const char *kStageNames[RT_MAX_STAGES] = {"mega",     "primary", "trace_primary",   "post_primary", "gen_direct", "trace_shadow",
+                                                 "trace_gi", "gen_gi",  "trace_gi_shadow", "combine",      "assemble",   ""};
 
 // ------------------------------------------------------------------------------------------------
 namespace {
@@ -440,7 +440,7 @@ int rt_render_frame(RtContext *c, const RtUniforms *uIn) {
     tg.motion = c->dMotion; tg.gpos = c->dGPos; tg.gnrm = c->dGNrm;
     const bool count = c->cfg.countWork != 0;
     int pipeline = c->cfg.pipeline;
-    if (pipeline == RT_PIPELINE_AUTO) pipeline = RT_PIPELINE_MEGAKERNEL;  // TODO wavefront
+    if (pipeline == RT_PIPELINE_AUTO) pipeline = (fr.u.useBVH == 1 && fr.sc.hasBVH && !count) ? RT_PIPELINE_WAVEFRONT : RT_PIPELINE_MEGAKERNEL;
     if (pipeline == RT_PIPELINE_WAVEFRONT && !(fr.u.useBVH == 1)) pipeline = RT_PIPELINE_MEGAKERNEL;   // analytic scene: pure ALU, megakernel only
     if (pipeline == RT_PIPELINE_WAVEFRONT) {
         int rc = rt_wave_render(c->wave, c, c->stream, c->dFrame, fr, tg, c->dCounters, count, std::max(c->treeDepth, 1));
@@ -521,9 +521,9 @@ int rt_assemble_gathered(RtContext *c, int which, const void *gatheredDev, void 
     (void)hipSetDevice(c->cfg.device);
     const int ch = (which == RT_TARGET_MOTION) ? 2 : 4;
     const size_t n = (size_t)c->g.W * c->g.H;
-    rt_stage_begin(c, 9);
+    rt_stage_begin(c, 10);
     hipLaunchKernelGGL(k_assemble, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, gatheredDev, dstDev, c->g, ch, c->nSlots * ch * 2);
-    rt_stage_end(c, 9, 1);
+    rt_stage_end(c, 10, 1);
     HIP_TRY(c, hipGetLastError());
     return RT_OK;
 }
@@ -565,7 +565,7 @@ int rt_get_stage_times(RtContext *c, RtStageTimes *out) {
     if (!c || !out) return RT_ERR_INVALID;
     (void)hipSetDevice(c->cfg.device);
     resolve_stage_events(c);
-    out->nStages = 10;
+    out->nStages = 11;
     out->frames = c->timedFrames;
     for (int i = 0; i < RT_MAX_STAGES; ++i) { out->ms[i] = c->stageMs[i]; out->launches[i] = c->stageLaunches[i]; }
     return RT_OK;

@@ -1,15 +1,629 @@
-// rt_wave.hip -- wavefront pipeline (placeholder while the megakernel path is brought up).
+// rt_wave.hip -- wavefront pipeline for BVH scenes (the production path on MI355X).
+//
+// One frame of rt.frag in BVH mode is cut into stages so that every traversal runs in a dedicated,
+// register-lean persistent kernel and all shading runs in dense ALU kernels:
+//
+//   primary        thread = pixel.  Ray generation + slab test against the root box.  Pixels whose
+//                  ray misses the scene box (the vast majority when the mesh is small on screen)
+//                  are finished here: sky x SPP, TAA resolve, 4 target stores.  The rest are
+//                  compacted (wave ballot, one atomic per wave) into the candidate list.
+//   trace_primary  persistent closest-hit traversal over the candidates (ray rebuilt from the pixel).
+//   post_primary   thread = candidate.  Misses are finished like above; hits are compacted into
+//                  the hit list {slot, t, triangle}.
+//   gen_direct     thread = (hit, sample).  Runs the reference's shading code with a tracer that
+//                  only RECORDS rays: 4 disk + sun + point shadow rays, the GI bounce ray, and
+//                  (sample 0) the AO rays.  Queues are slot-major: all "sun" rays of a chunk are
+//                  contiguous, so neighbouring lanes trace near-identical rays.
+//   trace_shadow   persistent any-hit traversal (direct shadows + AO as any-hit with tMax < radius)
+//   trace_gi       persistent closest-hit traversal of the bounce rays
+//   gen_gi         thread = (hit, sample): shadow rays at the bounce hit
+//   trace_gi_shadow
+//   combine        thread = hit: the reference's shading code again, now with a tracer that READS
+//                  the recorded visibilities / hits, in the reference's evaluation order (so the
+//                  sums are bit-identical to the megakernel and the oracle); TAA; stores.
+//
+// Persistent traversal ("ray scheduler"): a fixed grid of waves pulls rays from a global cursor.
+// When enough lanes of a wave have finished their ray (ballot + popcount), exactly those lanes
+// fetch new rays with ONE atomic for the wave and restart, so divergent ray lengths do not leave
+// the SIMD half empty.  Each lane's traversal stack is in LDS (stack[e*64 + lane], 8-byte entries:
+// deferred child + its entry distance).
 #include "rt_wave.hpp"
 
+#include <algorithm>
 #include <string>
 
 #include "../../include/rt_mi355.h"
 
-struct RtWave { std::string err; int cus; };
-RtWave *rt_wave_create(int cus) { RtWave *w = new RtWave(); w->cus = cus; return w; }
-void rt_wave_destroy(RtWave *w) { delete w; }
+#pragma clang fp contract(off)
+
+using namespace rtd;
+
+// stage ids (rt_stage_name in rt_api.hip)
+enum { ST_PRIMARY = 1, ST_TRACE_PRIMARY, ST_POST_PRIMARY, ST_GEN_DIRECT, ST_TRACE_SHADOW, ST_TRACE_GI, ST_GEN_GI, ST_TRACE_GI_SHADOW, ST_COMBINE };
+
+struct HitRec { uint32_t slot; float t; int tri; };
+
+struct WaveBuf {
+    // per frame
+    uint32_t *cand;          // candidate pixel slots
+    uint32_t *counts;        // [0] candidates, [1] hits, [2..] traced-ray tallies
+    uint32_t *heads;         // ray cursors, one per trace launch
+    float *primT;            // per candidate
+    int *primTri;
+    HitRec *hits;
+    // per chunk of CH hits
+    float4 *shO, *shD;       // shadow queue 1: (A + 6*SPP) slots x CH
+    uint8_t *occ1;
+    float4 *giO, *giD;       // bounce queue: SPP slots x CH
+    float *giT;
+    int *giTri;
+    float4 *sh2O, *sh2D;     // shadow queue 2: 6*SPP slots x CH
+    uint8_t *occ2;
+    uint32_t CH;             // chunk capacity (hits)
+    int A;                   // AO rays per hit (0 when AO is off)
+    int SPP;
+};
+
+namespace {
+
+constexpr int kRefillMin = 20;   // refill a wave's idle lanes once at least this many are idle
+
+// ---- finishing a pixel: frame average -> TAA -> 4 targets (rt.frag:184-196) -------------------
+RT_DEV void finish_pixel(const DevFrame *fr, const Targets &tg, int slot, int px, int py, V3 frameSum, V2 motionOut, V4 gpos, V4 gnrm) {
+    const RtUniforms &u = fr->u;
+    const int SPP = max(u.spp, 1);
+    V3 curr = frameSum / (float)SPP;
+    float uvx = ((float)px + 0.5f) / (float)fr->g.W, uvy = ((float)py + 0.5f) / (float)fr->g.H;
+    V2 taaMotion = (u.cameraMoved == 1) ? motionOut : mk2(0.0f, 0.0f);
+    HistoryTex hist;
+    hist.prev = tg.prev; hist.g = &fr->g; hist.slot = slot;
+    V4 taa = resolveTAA(u, curr, uvx, uvy, taaMotion, u.frameIndex, hist);
+    tg.color[slot] = pack_half4(taa);
+    tg.motion[slot] = pack_half2(motionOut);
+    tg.gpos[slot] = pack_half4(gpos);
+    tg.gnrm[slot] = pack_half4(gnrm);
+}
+RT_DEV void finish_miss(const DevFrame *fr, const Targets &tg, int slot, int px, int py, V3 dir) {
+    const RtUniforms &u = fr->u;
+    Frag F;
+    F.u = &u; F.sc = &fr->sc; F.fcx = (float)px + 0.5f; F.fcy = (float)py + 0.5f;
+    Work w;
+    V3 r = sky<false>(F, dir, w);
+    V3 frameSum = mk3(0.0f);
+    const int SPP = max(u.spp, 1);
+    for (int s = 0; s < SPP; ++s) frameSum = frameSum + r;   // the reference adds the same radiance SPP times
+    V2 motionOut = (u.cameraMoved == 1) ? mk2(4.0f, 4.0f) : mk2(0.0f, 0.0f);
+    finish_pixel(fr, tg, slot, px, py, frameSum, motionOut, mk4(0, 0, 0, 0), mk4(0, 0, 0, 0));
+}
+RT_DEV void slot_to_pixel(const FrameGeom &g, uint32_t slot, int &px, int &py) { pixel_of_slot(g, (int)(slot >> 8), (int)(slot & 255u), px, py); }
+
+// wave-level append: returns this lane's index in the list (valid where pred)
+RT_DEV uint32_t wave_append(bool pred, uint32_t *counter) {
+    unsigned long long m = __ballot(pred);
+    uint32_t n = (uint32_t)__popcll(m);
+    uint32_t base = 0;
+    if (n) {
+        int leader = __ffsll((long long)m) - 1;
+        if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(counter, n);
+        base = __shfl(base, leader, 64);
+    }
+    uint32_t lane = threadIdx.x & 63;
+    uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    return base + rank;
+}
+
+// ---- stage: primary ----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_primary(const DevFrame *__restrict__ fr, Targets tg, WaveBuf wb) {
+    const RtUniforms &u = fr->u;
+    int px, py;
+    const bool live = pixel_of_slot(fr->g, blockIdx.x, threadIdx.x, px, py);
+    const int slot = blockIdx.x * 256 + threadIdx.x;
+    bool cand = false;
+    if (live) {
+        V3 dir = primaryDir(u, (float)px + 0.5f, (float)py + 0.5f);
+        V3 rdInv = mk3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+        float tmin;
+        cand = fr->sc.hasBVH && slab(ld3(u.camPos), rdInv, ld3(fr->sc.rootMin), ld3(fr->sc.rootMax), tmin) && !(tmin > u.inf);
+        if (!cand) finish_miss(fr, tg, slot, px, py, dir);
+    }
+    uint32_t idx = wave_append(cand, &wb.counts[0]);
+    if (cand) wb.cand[idx] = (uint32_t)slot;
+}
+
+// ---- persistent traversal ----------------------------------------------------------------------
+// Ray sources.
+struct PrimarySrc {   // ray i = primary ray of candidate i
+    const DevFrame *fr;
+    const uint32_t *cand;
+    const uint32_t *count;
+    float *outT;
+    int *outTri;
+    RT_DEV uint32_t size() const { return *count; }
+    RT_DEV bool load(uint32_t i, V3 &ro, V3 &rd, float &tMax) const {
+        int px, py;
+        slot_to_pixel(fr->g, cand[i], px, py);
+        ro = ld3(fr->u.camPos);
+        rd = primaryDir(fr->u, (float)px + 0.5f, (float)py + 0.5f);
+        tMax = fr->u.inf;
+        return true;
+    }
+    RT_DEV void store_closest(uint32_t i, float t, int tri) const { outT[i] = t; outTri[i] = tri; }
+    RT_DEV void store_any(uint32_t, bool) const {}
+};
+struct QueueSrc {     // slot-major queue: ray r -> (slot = r / n, j = r % n) at [slot*CH + j], n = live hits of the chunk
+    const float4 *o, *d;
+    const uint32_t *hitCount;
+    uint32_t c0, CH, slots;
+    float *outT;
+    int *outTri;
+    uint8_t *outOcc;
+    RT_DEV uint32_t live() const { uint32_t h = *hitCount; return h > c0 ? min(h - c0, CH) : 0u; }
+    RT_DEV uint32_t size() const { return live() * slots; }
+    RT_DEV uint32_t addr(uint32_t r) const { uint32_t n = live(); return (r / n) * CH + (r % n); }
+    RT_DEV bool load(uint32_t r, V3 &ro, V3 &rd, float &tMax) const {
+        uint32_t a = addr(r);
+        float4 oo = o[a];
+        if (oo.w < 0.0f) return false;   // slot not used by this sample
+        float4 dd = d[a];
+        ro = f4xyz(oo); rd = f4xyz(dd); tMax = oo.w;
+        return true;
+    }
+    RT_DEV void store_closest(uint32_t r, float t, int tri) const { uint32_t a = addr(r); outT[a] = t; outTri[a] = tri; }
+    RT_DEV void store_any(uint32_t r, bool occ) const { outOcc[addr(r)] = occ ? 1 : 0; }
+};
+
+template <class Src, bool ANY, int STACK>
+__global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, Src src, uint32_t *head, uint32_t *tally) {
+    __shared__ StackEntry lds[4 * STACK * 64];
+    StackEntry *stk = &lds[(threadIdx.x >> 6) * STACK * 64 + (threadIdx.x & 63)];
+    const DevScene &sc = fr->sc;
+    const float eps = fr->u.eps, inf = fr->u.inf;
+    const uint32_t n = src.size();
+    const uint32_t lane = threadIdx.x & 63;
+
+    // per-lane ray state
+    V3 ro = mk3(0.0f), rd = mk3(0.0f), rdInv = mk3(0.0f);
+    float tBest = 0.0f;          // closest: best t so far; any: tMax
+    int triBest = -1;
+    int ref = 0, sp = 0;
+    uint32_t rayId = 0;
+    bool active = false;
+    bool exhausted = (n == 0);
+    uint32_t traced = 0;
+
+    for (;;) {
+        // ---- scheduler: hand new rays to idle lanes, one atomic per wave
+        unsigned long long idleMask = __ballot(!active);
+        int nIdle = __popcll(idleMask);
+        if (!exhausted && nIdle >= kRefillMin) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(head, (uint32_t)nIdle);
+            base = __shfl(base, 0, 64);
+            if (!active) {
+                uint32_t my = base + (uint32_t)__popcll(idleMask & ((1ull << lane) - 1ull));
+                if (my < n) {
+                    float tMax;
+                    if (src.load(my, ro, rd, tMax)) {
+                        traced++;
+                        rayId = my;
+                        rdInv = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+                        tBest = ANY ? tMax : inf;
+                        triBest = -1;
+                        sp = 0;
+                        ref = sc.rootRef;
+                        float tmin;
+                        bool in = sc.hasBVH && slab(ro, rdInv, ld3(sc.rootMin), ld3(sc.rootMax), tmin) && !(tmin > tBest);
+                        if (in) active = true;
+                        else if (ANY) src.store_any(my, false);
+                        else src.store_closest(my, inf, -1);
+                    }
+                }
+            }
+            if (base + (uint32_t)nIdle >= n) exhausted = true;
+            continue;   // lanes that drew a dead slot or a root miss may draw again
+        }
+        if (__ballot(active) == 0ull) {
+            if (exhausted) break;
+            continue;
+        }
+        // ---- one traversal step per active lane
+        if (active) {
+            bool pop = false;
+            if (ref >= 0) {
+                const float4 *nd = sc.wnodes + (size_t)ref * 4;
+                float4 a = nd[0], b = nd[1], c = nd[2], d = nd[3];
+                float tL, tR;
+                bool hitL = slab(ro, rdInv, f4xyz(a), f4xyz(b), tL) && tL <= tBest;
+                bool hitR = slab(ro, rdInv, f4xyz(c), f4xyz(d), tR) && tR <= tBest;
+                int refL = (int)f2u(a.w), refR = (int)f2u(b.w);
+                if (hitL && hitR) {
+                    bool leftFirst = tL < tR;
+                    StackEntry e;
+                    e.x = (uint32_t)(leftFirst ? refR : refL);
+                    e.y = f2u(leftFirst ? tR : tL);
+                    stk[sp * 64] = e;
+                    sp++;
+                    ref = leftFirst ? refL : refR;
+                } else if (hitL || hitR) {
+                    ref = hitL ? refL : refR;
+                } else pop = true;
+            } else {
+                int v = -ref - 1;
+                int first = v >> 3, count = (v & 7) + 1;
+                bool done = false;
+                for (int i = 0; i < count; ++i) {
+                    const float4 *t = sc.tris + (size_t)(first + i) * 3;
+                    float4 p0 = t[0], p1 = t[1], p2 = t[2];
+                    float tt;
+                    if (tri_hit(ro, rd, f4xyz(p0), f4xyz(p1), f4xyz(p2), eps, tBest, tt)) {
+                        if (ANY) { done = true; break; }
+                        tBest = tt;
+                        triBest = first + i;
+                    }
+                }
+                if (ANY && done) {
+                    src.store_any(rayId, true);
+                    active = false;
+                } else pop = true;
+            }
+            if (pop) {
+                bool found = false;
+                while (sp > 0) {
+                    sp--;
+                    StackEntry e = stk[sp * 64];
+                    if (!ANY && u2f(e.y) > tBest) continue;   // rt_bvh.glsl:208 cull
+                    ref = (int)e.x;
+                    found = true;
+                    break;
+                }
+                if (!found) {
+                    if (ANY) src.store_any(rayId, false);
+                    else src.store_closest(rayId, triBest >= 0 ? tBest : inf, triBest);
+                    active = false;
+                }
+            }
+        }
+    }
+    if (tally) {
+        uint32_t s = traced;
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        if (lane == 0 && s) atomicAdd(tally, s);
+    }
+}
+
+// ---- stage: post_primary -------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_post_primary(const DevFrame *__restrict__ fr, Targets tg, WaveBuf wb) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t n = wb.counts[0];
+    bool hit = false;
+    uint32_t slot = 0;
+    float t = 0.0f;
+    int tri = -1;
+    if (i < n) {
+        slot = wb.cand[i];
+        t = wb.primT[i];
+        tri = wb.primTri[i];
+        hit = tri >= 0;
+        if (!hit) {
+            int px, py;
+            slot_to_pixel(fr->g, slot, px, py);
+            finish_miss(fr, tg, (int)slot, px, py, primaryDir(fr->u, (float)px + 0.5f, (float)py + 0.5f));
+        }
+    }
+    uint32_t idx = wave_append(hit, &wb.counts[1]);
+    if (hit) { HitRec h; h.slot = slot; h.t = t; h.tri = tri; wb.hits[idx] = h; }
+}
+
+// ---- tracer policies ---------------------------------------------------------------------------
+RT_DEV float4 mkf4(V3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
+RT_DEV float below(float r) { return (r > 0.0f) ? u2f(f2u(r) - 1u) : -1.0f; }   // largest float < r (r > 0), else "no ray"
+
+struct GenDirectTracer {   // records first-generation rays of (hit j, sample s)
+    WaveBuf wb;
+    uint32_t j;
+    int s;
+    uint32_t shadowMask;
+    bool giCast;
+    RT_DEV bool shadow(int, int k, V3 ro, V3 rd, float tMax) {
+        uint32_t a = (uint32_t)(wb.A + s * 6 + k) * wb.CH + j;
+        wb.shO[a] = mkf4(ro, fmaxr(tMax, 0.0f));
+        wb.shD[a] = mkf4(rd, 0.0f);
+        shadowMask |= 1u << k;
+        return false;
+    }
+    RT_DEV int gi(V3 ro, V3 rd, V3 &, V3 &) {
+        uint32_t a = (uint32_t)s * wb.CH + j;
+        wb.giO[a] = mkf4(ro, 1.0f);
+        wb.giD[a] = mkf4(rd, 0.0f);
+        giCast = true;
+        return -1;
+    }
+    RT_DEV bool ao(int i, V3 org, V3 dir, float radius) {
+        uint32_t a = (uint32_t)i * wb.CH + j;
+        wb.shO[a] = mkf4(org, below(radius));   // closest t < radius  <=>  any hit with t <= pred(radius)
+        wb.shD[a] = mkf4(dir, 0.0f);
+        return false;
+    }
+};
+struct GenGiTracer {       // reads the bounce result, records the shadow rays at the bounce hit
+    WaveBuf wb;
+    const DevScene *sc;
+    float inf;
+    uint32_t j;
+    int s;
+    uint32_t shadowMask;
+    RT_DEV bool shadow(int seg, int k, V3 ro, V3 rd, float tMax) {
+        if (seg != SEG_GI_DIRECT) return false;
+        uint32_t a = (uint32_t)(s * 6 + k) * wb.CH + j;
+        wb.sh2O[a] = mkf4(ro, fmaxr(tMax, 0.0f));
+        wb.sh2D[a] = mkf4(rd, 0.0f);
+        shadowMask |= 1u << k;
+        return false;
+    }
+    RT_DEV int gi(V3 ro, V3 rd, V3 &hp, V3 &hn) {
+        uint32_t a = (uint32_t)s * wb.CH + j;
+        int tri = wb.giTri[a];
+        if (tri < 0) return 0;
+        hp = ro + rd * wb.giT[a];
+        hn = tri_normal(*sc, tri);
+        return 1;
+    }
+    RT_DEV bool ao(int, V3, V3, float) { return false; }
+};
+struct CombineTracer {     // reads everything
+    WaveBuf wb;
+    const DevScene *sc;
+    uint32_t j;
+    int s;
+    RT_DEV bool shadow(int seg, int k, V3, V3, float) {
+        return (seg == SEG_DIRECT) ? wb.occ1[(uint32_t)(wb.A + s * 6 + k) * wb.CH + j] != 0 : wb.occ2[(uint32_t)(s * 6 + k) * wb.CH + j] != 0;
+    }
+    RT_DEV int gi(V3 ro, V3 rd, V3 &hp, V3 &hn) {
+        uint32_t a = (uint32_t)s * wb.CH + j;
+        int tri = wb.giTri[a];
+        if (tri < 0) return 0;
+        hp = ro + rd * wb.giT[a];
+        hn = tri_normal(*sc, tri);
+        return 1;
+    }
+    RT_DEV bool ao(int i, V3, V3, float radius) { return radius > 0.0f && wb.occ1[(uint32_t)i * wb.CH + j] != 0; }
+};
+
+struct HitCtx { Frag F; V3 dir, hp, hn; int px, py; uint32_t slot; };
+RT_DEV HitCtx load_hit(const DevFrame *fr, const HitRec &h) {
+    HitCtx c;
+    c.slot = h.slot;
+    slot_to_pixel(fr->g, h.slot, c.px, c.py);
+    c.F.u = &fr->u; c.F.sc = &fr->sc; c.F.fcx = (float)c.px + 0.5f; c.F.fcy = (float)c.py + 0.5f;
+    c.dir = primaryDir(fr->u, c.F.fcx, c.F.fcy);
+    c.hp = ld3(fr->u.camPos) + c.dir * h.t;
+    c.hn = tri_normal(fr->sc, h.tri);
+    return c;
+}
+RT_DEV uint32_t chunk_live(const WaveBuf &wb, uint32_t c0) { uint32_t h = wb.counts[1]; return h > c0 ? min(h - c0, wb.CH) : 0u; }
+
+// ---- stage: gen_direct  (thread = (hit j, sample s), s-major so a wave shares s) -----------------
+__global__ __launch_bounds__(256) void k_gen_direct(const DevFrame *__restrict__ fr, WaveBuf wb, uint32_t c0) {
+    const RtUniforms &u = fr->u;
+    const uint32_t live = chunk_live(wb, c0);
+    const uint32_t tid = blockIdx.x * 256 + threadIdx.x;
+    if (live == 0 || tid >= live * (uint32_t)wb.SPP) return;
+    const int s = (int)(tid / live);
+    const uint32_t j = tid % live;
+    HitCtx c = load_hit(fr, wb.hits[c0 + j]);
+    const int SPP = max(u.spp, 1);
+    const int seed = (int)((uint32_t)u.frameIndex * (uint32_t)SPP + (uint32_t)s);
+    GenDirectTracer tr;
+    tr.wb = wb; tr.j = j; tr.s = s; tr.shadowMask = 0; tr.giCast = false;
+    (void)directLightBVH(tr, c.F, SEG_DIRECT, c.hp, c.hn, seed, -c.dir);
+    for (int k = 4; k < 6; ++k)   // sun / point rays are conditional (rt_lighting.glsl:123,194)
+        if (!(tr.shadowMask & (1u << k))) wb.shO[(uint32_t)(wb.A + s * 6 + k) * wb.CH + j] = make_float4(0, 0, 0, -1.0f);
+    Work w;
+    if (u.enableGI == 1) (void)oneBounceGIBVH<GenDirectTracer, false>(tr, c.F, c.hp, c.hn, u.frameIndex, seed, w);
+    if (!tr.giCast) wb.giO[(uint32_t)s * wb.CH + j] = make_float4(0, 0, 0, -1.0f);
+    if (s == 0 && wb.A > 0) (void)computeAO_BVH(tr, c.F, c.hp, c.hn, u.frameIndex);
+}
+
+// ---- stage: gen_gi -------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gen_gi(const DevFrame *__restrict__ fr, WaveBuf wb, uint32_t c0) {
+    const RtUniforms &u = fr->u;
+    const uint32_t live = chunk_live(wb, c0);
+    const uint32_t tid = blockIdx.x * 256 + threadIdx.x;
+    if (live == 0 || tid >= live * (uint32_t)wb.SPP) return;
+    const int s = (int)(tid / live);
+    const uint32_t j = tid % live;
+    GenGiTracer tr;
+    tr.wb = wb; tr.sc = &fr->sc; tr.inf = u.inf; tr.j = j; tr.s = s; tr.shadowMask = 0;
+    if (wb.giO[(uint32_t)s * wb.CH + j].w >= 0.0f && wb.giTri[(uint32_t)s * wb.CH + j] >= 0) {
+        HitCtx c = load_hit(fr, wb.hits[c0 + j]);
+        const int SPP = max(u.spp, 1);
+        const int seed = (int)((uint32_t)u.frameIndex * (uint32_t)SPP + (uint32_t)s);
+        Work w;
+        (void)oneBounceGIBVH<GenGiTracer, false>(tr, c.F, c.hp, c.hn, u.frameIndex, seed, w);
+    }
+    for (int k = 0; k < 6; ++k)
+        if (!(tr.shadowMask & (1u << k))) wb.sh2O[(uint32_t)(s * 6 + k) * wb.CH + j] = make_float4(0, 0, 0, -1.0f);
+}
+
+// ---- stage: combine (thread = hit) ---------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_combine(const DevFrame *__restrict__ fr, Targets tg, WaveBuf wb, uint32_t c0) {
+    const RtUniforms &u = fr->u;
+    const uint32_t live = chunk_live(wb, c0);
+    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= live) return;
+    HitCtx c = load_hit(fr, wb.hits[c0 + j]);
+    const int SPP = max(u.spp, 1);
+    CombineTracer tr;
+    tr.wb = wb; tr.sc = &fr->sc; tr.j = j; tr.s = 0;
+    Work w;
+    V2 prevNDC = ndcFromWorld(c.hp, u.prevViewProj), currNDC = ndcFromWorld(c.hp, u.currViewProj);
+    V2 motionOut = mk2(currNDC.x - prevNDC.x, currNDC.y - prevNDC.y);
+    V3 nn = normalize(c.hn);
+    float ao = 1.0f;
+    if (u.enableAO == 1) ao = computeAO_BVH(tr, c.F, c.hp, c.hn, u.frameIndex);
+    V3 frameSum = mk3(0.0f);
+    for (int s = 0; s < SPP; ++s) {
+        tr.s = s;
+        int seed = (int)((uint32_t)u.frameIndex * (uint32_t)SPP + (uint32_t)s);
+        frameSum = frameSum + shadeSampleBVH<CombineTracer, false>(tr, c.F, c.hp, c.hn, -c.dir, seed, ao, w);
+    }
+    finish_pixel(fr, tg, (int)c.slot, c.px, c.py, frameSum, motionOut, mk4(c.hp.x, c.hp.y, c.hp.z, 1.0f), mk4(nn.x, nn.y, nn.z, 0.0f));
+}
+
+template <class Src, bool ANY>
+void launch_trace(hipStream_t st, int blocks, int depth, const DevFrame *fr, Src src, uint32_t *head, uint32_t *tally) {
+    dim3 g((unsigned)blocks), b(256);
+    if (depth <= 16) hipLaunchKernelGGL((k_trace<Src, ANY, 16>), g, b, 0, st, fr, src, head, tally);
+    else if (depth <= 24) hipLaunchKernelGGL((k_trace<Src, ANY, 24>), g, b, 0, st, fr, src, head, tally);
+    else hipLaunchKernelGGL((k_trace<Src, ANY, 32>), g, b, 0, st, fr, src, head, tally);
+}
+
+}  // namespace
+
+// -------------------------------------------------------------------------------------------------
+struct RtWave {
+    std::string err;
+    int cus = 256;
+    size_t budgetBytes = (size_t)8 << 30;   // ray-queue budget per context; 288 GB of HBM make this cheap
+    // allocations
+    size_t slotsCap = 0;      // per-frame arrays sized for this many pixel slots
+    size_t chunkBytes = 0;    // bytes of the per-chunk arena
+    void *frameArena = nullptr, *chunkArena = nullptr;
+    uint32_t *counts = nullptr, *heads = nullptr;
+};
+
+RtWave *rt_wave_create(int cus) {
+    RtWave *w = new RtWave();
+    w->cus = cus > 0 ? cus : 256;
+    if (const char *e = getenv("RT_QUEUE_BUDGET_MB")) w->budgetBytes = (size_t)atoll(e) << 20;
+    return w;
+}
+void rt_wave_destroy(RtWave *w) {
+    if (!w) return;
+    if (w->frameArena) (void)hipFree(w->frameArena);
+    if (w->chunkArena) (void)hipFree(w->chunkArena);
+    if (w->counts) (void)hipFree(w->counts);
+    if (w->heads) (void)hipFree(w->heads);
+    delete w;
+}
 const char *rt_wave_error(const RtWave *w) { return w->err.c_str(); }
-int rt_wave_render(RtWave *w, RtContext *, hipStream_t, const rtd::DevFrame *, const rtd::DevFrame &, rtd::Targets, unsigned long long *, bool, int) {
-    w->err = "wavefront pipeline not built";
-    return RT_ERR_UNSUPPORTED;
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+#define W_TRY(expr)                                                                   \
+    do {                                                                              \
+        hipError_t e_ = (expr);                                                       \
+        if (e_ != hipSuccess) { w->err = std::string(#expr) + ": " + hipGetErrorString(e_); return RT_ERR_HIP; } \
+    } while (0)
+
+int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dFrame, const DevFrame &host, Targets tg,
+                   unsigned long long *, bool count, int treeDepth) {
+    if (count) { w->err = "work counters are produced by the megakernel pipeline (RT_PIPELINE_MEGAKERNEL)"; return RT_ERR_UNSUPPORTED; }
+    const RtUniforms &u = host.u;
+    const size_t nSlots = (size_t)std::max(host.g.nLocalTiles, 1) * 256;
+    const int SPP = std::max(u.spp, 1);
+    const int A = (u.enableAO == 1) ? std::max(u.aoSamples, 0) : 0;
+    const int S1 = A + 6 * SPP, S2 = 6 * SPP;
+
+    if (!w->counts) { W_TRY(hipMalloc(&w->counts, 64 * sizeof(uint32_t))); W_TRY(hipMalloc(&w->heads, 4096 * sizeof(uint32_t))); }
+    // per-frame arena: cand, primT, primTri, hits
+    if (w->slotsCap < nSlots) {
+        if (w->frameArena) (void)hipFree(w->frameArena);
+        w->frameArena = nullptr;
+        W_TRY(hipMalloc(&w->frameArena, nSlots * (4 + 4 + 4 + sizeof(HitRec))));
+        w->slotsCap = nSlots;
+    }
+    // chunk capacity from the budget
+    const size_t perHit = (size_t)(S1 + SPP + S2) * 32 + (size_t)S1 + (size_t)SPP * 8 + (size_t)S2;
+    size_t CH = std::min(nSlots, std::max<size_t>(w->budgetBytes / perHit, 4096));
+    CH = align_up(CH, 256);
+    const size_t need = align_up(CH * (size_t)S1 * 32, 256) + align_up(CH * (size_t)S1, 256) + align_up(CH * (size_t)SPP * 32, 256) +
+                        align_up(CH * (size_t)SPP * 8, 256) + align_up(CH * (size_t)S2 * 32, 256) + align_up(CH * (size_t)S2, 256) + 4096;
+    if (w->chunkBytes < need) {
+        if (w->chunkArena) (void)hipFree(w->chunkArena);
+        w->chunkArena = nullptr;
+        w->chunkBytes = 0;
+        W_TRY(hipMalloc(&w->chunkArena, need));
+        w->chunkBytes = need;
+    }
+    WaveBuf wb;
+    {
+        char *p = (char *)w->frameArena;
+        wb.cand = (uint32_t *)p; p += nSlots * 4;
+        wb.primT = (float *)p; p += nSlots * 4;
+        wb.primTri = (int *)p; p += nSlots * 4;
+        wb.hits = (HitRec *)p;
+        char *q = (char *)w->chunkArena;
+        auto take = [&](size_t bytes) { char *r = q; q += align_up(bytes, 256); return r; };
+        wb.shO = (float4 *)take(CH * (size_t)S1 * 16); wb.shD = (float4 *)take(CH * (size_t)S1 * 16);
+        wb.occ1 = (uint8_t *)take(CH * (size_t)S1);
+        wb.giO = (float4 *)take(CH * (size_t)SPP * 16); wb.giD = (float4 *)take(CH * (size_t)SPP * 16);
+        wb.giT = (float *)take(CH * (size_t)SPP * 4); wb.giTri = (int *)take(CH * (size_t)SPP * 4);
+        wb.sh2O = (float4 *)take(CH * (size_t)S2 * 16); wb.sh2D = (float4 *)take(CH * (size_t)S2 * 16);
+        wb.occ2 = (uint8_t *)take(CH * (size_t)S2);
+    }
+    wb.counts = w->counts; wb.heads = w->heads;
+    wb.CH = (uint32_t)CH; wb.A = A; wb.SPP = SPP;
+    const int nChunks = (int)((nSlots + CH - 1) / CH);
+    if (1 + nChunks * 3 > 4096) { w->err = "too many chunks for the cursor table; raise RT_QUEUE_BUDGET_MB"; return RT_ERR_UNSUPPORTED; }
+
+    W_TRY(hipMemsetAsync(w->counts, 0, 64 * sizeof(uint32_t), st));
+    W_TRY(hipMemsetAsync(w->heads, 0, (size_t)(1 + nChunks * 3) * sizeof(uint32_t), st));
+    const int traceBlocks = w->cus * 5;
+    const unsigned tiles = (unsigned)std::max(host.g.nLocalTiles, 0);
+    if (tiles == 0) return RT_OK;
+
+    rt_stage_begin(ctx, ST_PRIMARY);
+    hipLaunchKernelGGL(k_primary, dim3(tiles), dim3(256), 0, st, dFrame, tg, wb);
+    rt_stage_end(ctx, ST_PRIMARY, 1);
+
+    rt_stage_begin(ctx, ST_TRACE_PRIMARY);
+    PrimarySrc ps;
+    ps.fr = dFrame; ps.cand = wb.cand; ps.count = &wb.counts[0]; ps.outT = wb.primT; ps.outTri = wb.primTri;
+    launch_trace<PrimarySrc, false>(st, traceBlocks, treeDepth, dFrame, ps, &wb.heads[0], &wb.counts[2]);
+    rt_stage_end(ctx, ST_TRACE_PRIMARY, 1);
+
+    rt_stage_begin(ctx, ST_POST_PRIMARY);
+    hipLaunchKernelGGL(k_post_primary, dim3(tiles), dim3(256), 0, st, dFrame, tg, wb);
+    rt_stage_end(ctx, ST_POST_PRIMARY, 1);
+
+    for (int c = 0; c < nChunks; ++c) {
+        const uint32_t c0 = (uint32_t)((size_t)c * CH);
+        const unsigned gridHS = (unsigned)((CH * (size_t)SPP + 255) / 256), gridH = (unsigned)((CH + 255) / 256);
+        rt_stage_begin(ctx, ST_GEN_DIRECT);
+        hipLaunchKernelGGL(k_gen_direct, dim3(gridHS), dim3(256), 0, st, dFrame, wb, c0);
+        rt_stage_end(ctx, ST_GEN_DIRECT, 1);
+
+        QueueSrc q1;
+        q1.o = wb.shO; q1.d = wb.shD; q1.hitCount = &wb.counts[1]; q1.c0 = c0; q1.CH = wb.CH; q1.slots = (uint32_t)S1;
+        q1.outT = nullptr; q1.outTri = nullptr; q1.outOcc = wb.occ1;
+        rt_stage_begin(ctx, ST_TRACE_SHADOW);
+        launch_trace<QueueSrc, true>(st, traceBlocks, treeDepth, dFrame, q1, &wb.heads[1 + c * 3 + 0], &wb.counts[3]);
+        rt_stage_end(ctx, ST_TRACE_SHADOW, 1);
+
+        if (u.enableGI == 1) {
+            QueueSrc qg;
+            qg.o = wb.giO; qg.d = wb.giD; qg.hitCount = &wb.counts[1]; qg.c0 = c0; qg.CH = wb.CH; qg.slots = (uint32_t)SPP;
+            qg.outT = wb.giT; qg.outTri = wb.giTri; qg.outOcc = nullptr;
+            rt_stage_begin(ctx, ST_TRACE_GI);
+            launch_trace<QueueSrc, false>(st, traceBlocks, treeDepth, dFrame, qg, &wb.heads[1 + c * 3 + 1], &wb.counts[4]);
+            rt_stage_end(ctx, ST_TRACE_GI, 1);
+
+            rt_stage_begin(ctx, ST_GEN_GI);
+            hipLaunchKernelGGL(k_gen_gi, dim3(gridHS), dim3(256), 0, st, dFrame, wb, c0);
+            rt_stage_end(ctx, ST_GEN_GI, 1);
+
+            QueueSrc q2;
+            q2.o = wb.sh2O; q2.d = wb.sh2D; q2.hitCount = &wb.counts[1]; q2.c0 = c0; q2.CH = wb.CH; q2.slots = (uint32_t)S2;
+            q2.outT = nullptr; q2.outTri = nullptr; q2.outOcc = wb.occ2;
+            rt_stage_begin(ctx, ST_TRACE_GI_SHADOW);
+            launch_trace<QueueSrc, true>(st, traceBlocks, treeDepth, dFrame, q2, &wb.heads[1 + c * 3 + 2], &wb.counts[5]);
+            rt_stage_end(ctx, ST_TRACE_GI_SHADOW, 1);
+        }
+        rt_stage_begin(ctx, ST_COMBINE);
+        hipLaunchKernelGGL(k_combine, dim3(gridH), dim3(256), 0, st, dFrame, tg, wb, c0);
+        rt_stage_end(ctx, ST_COMBINE, 1);
+    }
+    W_TRY(hipGetLastError());
+    return RT_OK;
 }
