@@ -57,8 +57,9 @@ struct WaveBuf {
     float4 *giO, *giD;       // bounce queue: SPP slots x CH
     float *giT;
     int *giTri;
-    float4 *sh2O, *sh2D;     // shadow queue 2: 6*SPP slots x CH
+    float4 *sh2O, *sh2D;     // shadow queue 2: 6 slots x (CH*SPP), entries compacted over the (hit, sample) pairs whose bounce hit
     uint8_t *occ2;
+    int *giPos;              // per (sample, hit): entry in queue 2, -1 when the bounce ray missed or was not cast
     uint32_t CH;             // chunk capacity (hits)
     int A;                   // AO rays per hit (0 when AO is off)
     int SPP;
@@ -66,7 +67,6 @@ struct WaveBuf {
 
 namespace {
 
-constexpr int kRefillMin = 20;   // refill a wave's idle lanes once at least this many are idle
 
 // ---- finishing a pixel: frame average -> TAA -> 4 targets (rt.frag:184-196) -------------------
 RT_DEV void finish_pixel(const DevFrame *fr, const Targets &tg, int slot, int px, int py, V3 frameSum, V2 motionOut, V4 gpos, V4 gnrm) {
@@ -112,6 +112,27 @@ RT_DEV uint32_t wave_append(bool pred, uint32_t *counter) {
     return base + rank;
 }
 
+// block-level append (all 256 threads must call): ONE atomic per workgroup on the list counter -- a single
+// counter word sustains only ~88 M atomics/s, which per-wave appends of a 1080p frame would saturate.
+RT_DEV uint32_t block_append(bool pred, uint32_t *counter) {
+    __shared__ uint32_t s_cnt[4];
+    __shared__ uint32_t s_base;
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned long long m = __ballot(pred);
+    if (lane == 0) s_cnt[wv] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        s_base = tot ? atomicAdd(counter, tot) : 0u;
+    }
+    __syncthreads();
+    uint32_t off = s_base;
+    for (uint32_t i = 0; i < wv; ++i) off += s_cnt[i];
+    uint32_t r = off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    __syncthreads();   // s_cnt / s_base may be reused by a second append in the same kernel
+    return r;
+}
+
 // ---- stage: primary ----------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_primary(const DevFrame *__restrict__ fr, Targets tg, WaveBuf wb) {
     const RtUniforms &u = fr->u;
@@ -126,7 +147,7 @@ __global__ __launch_bounds__(256) void k_primary(const DevFrame *__restrict__ fr
         cand = fr->sc.hasBVH && slab(ld3(u.camPos), rdInv, ld3(fr->sc.rootMin), ld3(fr->sc.rootMax), tmin) && !(tmin > u.inf);
         if (!cand) finish_miss(fr, tg, slot, px, py, dir);
     }
-    uint32_t idx = wave_append(cand, &wb.counts[0]);
+    uint32_t idx = block_append(cand, &wb.counts[0]);
     if (cand) wb.cand[idx] = (uint32_t)slot;
 }
 
@@ -150,16 +171,16 @@ struct PrimarySrc {   // ray i = primary ray of candidate i
     RT_DEV void store_closest(uint32_t i, float t, int tri) const { outT[i] = t; outTri[i] = tri; }
     RT_DEV void store_any(uint32_t, bool) const {}
 };
-struct QueueSrc {     // slot-major queue: ray r -> (slot = r / n, j = r % n) at [slot*CH + j], n = live hits of the chunk
+struct QueueSrc {     // slot-major queue: ray r -> (slot = r / n, j = r % n) at [slot*stride + j], n = live entries
     const float4 *o, *d;
-    const uint32_t *hitCount;
-    uint32_t c0, CH, slots;
+    const uint32_t *liveCount;   // device counter the live entry count derives from
+    uint32_t c0, cap, stride, slots;
     float *outT;
     int *outTri;
     uint8_t *outOcc;
-    RT_DEV uint32_t live() const { uint32_t h = *hitCount; return h > c0 ? min(h - c0, CH) : 0u; }
+    RT_DEV uint32_t live() const { uint32_t h = *liveCount; return h > c0 ? min(h - c0, cap) : 0u; }
     RT_DEV uint32_t size() const { return live() * slots; }
-    RT_DEV uint32_t addr(uint32_t r) const { uint32_t n = live(); return (r / n) * CH + (r % n); }
+    RT_DEV uint32_t addr(uint32_t r) const { uint32_t n = live(); return (r / n) * stride + (r % n); }
     RT_DEV bool load(uint32_t r, V3 &ro, V3 &rd, float &tMax) const {
         uint32_t a = addr(r);
         float4 oo = o[a];
@@ -172,14 +193,23 @@ struct QueueSrc {     // slot-major queue: ray r -> (slot = r / n, j = r % n) at
     RT_DEV void store_any(uint32_t r, bool occ) const { outOcc[addr(r)] = occ ? 1 : 0; }
 };
 
+// Tunables of the scheduler (overridable per context through RT_REFILL_MIN / RT_MIN_SEARCH for experiments).
+struct TraceTune { int refillMin; int minSearch; int chunk; };
+
+template <bool ANY> struct StackOf { typedef StackEntry type; };          // closest: {deferred child, its entry distance}
+template <> struct StackOf<true> { typedef uint32_t type; };              // any-hit: the pop-time cull never fires (tMax is constant)
+
 template <class Src, bool ANY, int STACK>
-__global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, Src src, uint32_t *head, uint32_t *tally) {
-    __shared__ StackEntry lds[4 * STACK * 64];
-    StackEntry *stk = &lds[(threadIdx.x >> 6) * STACK * 64 + (threadIdx.x & 63)];
+__global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, Src src, uint32_t *head, uint32_t *tally, TraceTune tune) {
+    typedef typename StackOf<ANY>::type Entry;
+    __shared__ Entry lds[4 * STACK * 64];
+    Entry *stk = &lds[(threadIdx.x >> 6) * STACK * 64 + (threadIdx.x & 63)];
     const DevScene &sc = fr->sc;
     const float eps = fr->u.eps, inf = fr->u.inf;
     const uint32_t n = src.size();
     const uint32_t lane = threadIdx.x & 63;
+    // run length per reservation: ~8 runs per wave, so the tail stays balanced and the cursor stays cold
+    const uint32_t chunk = max(64u, min((uint32_t)tune.chunk, n / (gridDim.x * 4u * 8u)));
 
     // per-lane ray state
     V3 ro = mk3(0.0f), rd = mk3(0.0f), rdInv = mk3(0.0f);
@@ -190,18 +220,52 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
     bool active = false;
     bool exhausted = (n == 0);
     uint32_t traced = 0;
+    uint32_t runNext = 0, runEnd = 0;   // wave-uniform: this wave's reserved run of ray indices
+
+    // pop the next subtree of this lane's ray, or retire the ray
+    auto pop_or_finish = [&]() {
+        bool found = false;
+        while (sp > 0) {
+            sp--;
+            if (ANY) {
+                ref = (int)((const uint32_t *)stk)[sp * 64 * (sizeof(Entry) / 4)];
+                found = true;
+                break;
+            } else {
+                StackEntry e = ((const StackEntry *)stk)[sp * 64];
+                if (u2f(e.y) > tBest) continue;   // rt_bvh.glsl:208 cull
+                ref = (int)e.x;
+                found = true;
+                break;
+            }
+        }
+        if (!found) {
+            if (ANY) src.store_any(rayId, false);
+            else src.store_closest(rayId, triBest >= 0 ? tBest : inf, triBest);
+            active = false;
+        }
+    };
 
     for (;;) {
-        // ---- scheduler: hand new rays to idle lanes, one atomic per wave
+        // ---- scheduler: idle lanes take the next rays of this wave's reserved run; a new run of
+        // `tune.chunk` consecutive rays costs ONE atomic on the global cursor (a single cursor word
+        // saturates near 88 M atomics/s on MI355X, so per-refill atomics would bound the kernel).
         unsigned long long idleMask = __ballot(!active);
         int nIdle = __popcll(idleMask);
-        if (!exhausted && nIdle >= kRefillMin) {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(head, (uint32_t)nIdle);
-            base = __shfl(base, 0, 64);
+        if (!exhausted && nIdle >= tune.refillMin) {
+            if (runNext >= runEnd) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(head, chunk);
+                base = __shfl(base, 0, 64);
+                runNext = base;
+                runEnd = min(base + chunk, n);
+                if (base >= n) { exhausted = true; continue; }
+            }
+            const uint32_t take = min((uint32_t)nIdle, runEnd - runNext);
             if (!active) {
-                uint32_t my = base + (uint32_t)__popcll(idleMask & ((1ull << lane) - 1ull));
-                if (my < n) {
+                uint32_t rank = (uint32_t)__popcll(idleMask & ((1ull << lane) - 1ull));
+                if (rank < take) {
+                    uint32_t my = runNext + rank;
                     float tMax;
                     if (src.load(my, ro, rd, tMax)) {
                         traced++;
@@ -219,17 +283,20 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
                     }
                 }
             }
-            if (base + (uint32_t)nIdle >= n) exhausted = true;
+            runNext += take;
             continue;   // lanes that drew a dead slot or a root miss may draw again
         }
         if (__ballot(active) == 0ull) {
             if (exhausted) break;
             continue;
         }
-        // ---- one traversal step per active lane
-        if (active) {
-            bool pop = false;
-            if (ref >= 0) {
+        // ---- phase 1: walk inner nodes until (almost) every live lane holds a leaf
+        for (;;) {
+            const bool searching = active && ref >= 0;
+            const unsigned long long sm = __ballot(searching);
+            if (sm == 0ull) break;
+            if (__popcll(sm) < tune.minSearch && __ballot(active && ref < 0) != 0ull) break;   // keep the leaf phase dense
+            if (searching) {
                 const float4 *nd = sc.wnodes + (size_t)ref * 4;
                 float4 a = nd[0], b = nd[1], c = nd[2], d = nd[3];
                 float tL, tR;
@@ -238,50 +305,40 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
                 int refL = (int)f2u(a.w), refR = (int)f2u(b.w);
                 if (hitL && hitR) {
                     bool leftFirst = tL < tR;
-                    StackEntry e;
-                    e.x = (uint32_t)(leftFirst ? refR : refL);
-                    e.y = f2u(leftFirst ? tR : tL);
-                    stk[sp * 64] = e;
+                    if (ANY) {
+                        ((uint32_t *)stk)[sp * 64 * (sizeof(Entry) / 4)] = (uint32_t)(leftFirst ? refR : refL);
+                    } else {
+                        StackEntry e;
+                        e.x = (uint32_t)(leftFirst ? refR : refL);
+                        e.y = f2u(leftFirst ? tR : tL);
+                        ((StackEntry *)stk)[sp * 64] = e;
+                    }
                     sp++;
                     ref = leftFirst ? refL : refR;
                 } else if (hitL || hitR) {
                     ref = hitL ? refL : refR;
-                } else pop = true;
-            } else {
-                int v = -ref - 1;
-                int first = v >> 3, count = (v & 7) + 1;
-                bool done = false;
-                for (int i = 0; i < count; ++i) {
-                    const float4 *t = sc.tris + (size_t)(first + i) * 3;
-                    float4 p0 = t[0], p1 = t[1], p2 = t[2];
-                    float tt;
-                    if (tri_hit(ro, rd, f4xyz(p0), f4xyz(p1), f4xyz(p2), eps, tBest, tt)) {
-                        if (ANY) { done = true; break; }
-                        tBest = tt;
-                        triBest = first + i;
-                    }
-                }
-                if (ANY && done) {
-                    src.store_any(rayId, true);
-                    active = false;
-                } else pop = true;
+                } else pop_or_finish();
             }
-            if (pop) {
-                bool found = false;
-                while (sp > 0) {
-                    sp--;
-                    StackEntry e = stk[sp * 64];
-                    if (!ANY && u2f(e.y) > tBest) continue;   // rt_bvh.glsl:208 cull
-                    ref = (int)e.x;
-                    found = true;
-                    break;
-                }
-                if (!found) {
-                    if (ANY) src.store_any(rayId, false);
-                    else src.store_closest(rayId, triBest >= 0 ? tBest : inf, triBest);
-                    active = false;
+        }
+        // ---- phase 2: leaves
+        if (active && ref < 0) {
+            int v = -ref - 1;
+            int first = v >> 3, count = (v & 7) + 1;
+            bool done = false;
+            for (int i = 0; i < count; ++i) {
+                const float4 *t = sc.tris + (size_t)(first + i) * 3;
+                float4 p0 = t[0], p1 = t[1], p2 = t[2];
+                float tt;
+                if (tri_hit(ro, rd, f4xyz(p0), f4xyz(p1), f4xyz(p2), eps, tBest, tt)) {
+                    if (ANY) { done = true; break; }
+                    tBest = tt;
+                    triBest = first + i;
                 }
             }
+            if (ANY && done) {
+                src.store_any(rayId, true);
+                active = false;
+            } else pop_or_finish();
         }
     }
     if (tally) {
@@ -310,7 +367,7 @@ __global__ __launch_bounds__(256) void k_post_primary(const DevFrame *__restrict
             finish_miss(fr, tg, (int)slot, px, py, primaryDir(fr->u, (float)px + 0.5f, (float)py + 0.5f));
         }
     }
-    uint32_t idx = wave_append(hit, &wb.counts[1]);
+    uint32_t idx = block_append(hit, &wb.counts[1]);
     if (hit) { HitRec h; h.slot = slot; h.t = t; h.tri = tri; wb.hits[idx] = h; }
 }
 
@@ -351,10 +408,11 @@ struct GenGiTracer {       // reads the bounce result, records the shadow rays a
     float inf;
     uint32_t j;
     int s;
+    uint32_t pos;
     uint32_t shadowMask;
     RT_DEV bool shadow(int seg, int k, V3 ro, V3 rd, float tMax) {
         if (seg != SEG_GI_DIRECT) return false;
-        uint32_t a = (uint32_t)(s * 6 + k) * wb.CH + j;
+        uint32_t a = (uint32_t)k * (wb.CH * (uint32_t)wb.SPP) + pos;
         wb.sh2O[a] = mkf4(ro, fmaxr(tMax, 0.0f));
         wb.sh2D[a] = mkf4(rd, 0.0f);
         shadowMask |= 1u << k;
@@ -376,7 +434,8 @@ struct CombineTracer {     // reads everything
     uint32_t j;
     int s;
     RT_DEV bool shadow(int seg, int k, V3, V3, float) {
-        return (seg == SEG_DIRECT) ? wb.occ1[(uint32_t)(wb.A + s * 6 + k) * wb.CH + j] != 0 : wb.occ2[(uint32_t)(s * 6 + k) * wb.CH + j] != 0;
+        if (seg == SEG_DIRECT) return wb.occ1[(uint32_t)(wb.A + s * 6 + k) * wb.CH + j] != 0;
+        return wb.occ2[(uint32_t)k * (wb.CH * (uint32_t)wb.SPP) + (uint32_t)wb.giPos[(uint32_t)s * wb.CH + j]] != 0;
     }
     RT_DEV int gi(V3 ro, V3 rd, V3 &hp, V3 &hn) {
         uint32_t a = (uint32_t)s * wb.CH + j;
@@ -425,24 +484,28 @@ __global__ __launch_bounds__(256) void k_gen_direct(const DevFrame *__restrict__
 }
 
 // ---- stage: gen_gi -------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_gen_gi(const DevFrame *__restrict__ fr, WaveBuf wb, uint32_t c0) {
+__global__ __launch_bounds__(256) void k_gen_gi(const DevFrame *__restrict__ fr, WaveBuf wb, uint32_t c0, uint32_t *giCount) {
     const RtUniforms &u = fr->u;
     const uint32_t live = chunk_live(wb, c0);
     const uint32_t tid = blockIdx.x * 256 + threadIdx.x;
-    if (live == 0 || tid >= live * (uint32_t)wb.SPP) return;
-    const int s = (int)(tid / live);
-    const uint32_t j = tid % live;
+    const bool mine = live != 0 && tid < live * (uint32_t)wb.SPP;
+    const int s = mine ? (int)(tid / live) : 0;
+    const uint32_t j = mine ? tid % live : 0;
+    const uint32_t a = (uint32_t)s * wb.CH + j;
+    const bool bounced = mine && wb.giO[a].w >= 0.0f && wb.giTri[a] >= 0;
+    const uint32_t pos = block_append(bounced, giCount);   // compact the (hit, sample) pairs that need second-generation rays
+    if (!mine) return;
+    wb.giPos[a] = bounced ? (int)pos : -1;
+    if (!bounced) return;
     GenGiTracer tr;
-    tr.wb = wb; tr.sc = &fr->sc; tr.inf = u.inf; tr.j = j; tr.s = s; tr.shadowMask = 0;
-    if (wb.giO[(uint32_t)s * wb.CH + j].w >= 0.0f && wb.giTri[(uint32_t)s * wb.CH + j] >= 0) {
-        HitCtx c = load_hit(fr, wb.hits[c0 + j]);
-        const int SPP = max(u.spp, 1);
-        const int seed = (int)((uint32_t)u.frameIndex * (uint32_t)SPP + (uint32_t)s);
-        Work w;
-        (void)oneBounceGIBVH<GenGiTracer, false>(tr, c.F, c.hp, c.hn, u.frameIndex, seed, w);
-    }
+    tr.wb = wb; tr.sc = &fr->sc; tr.inf = u.inf; tr.j = j; tr.s = s; tr.pos = pos; tr.shadowMask = 0;
+    HitCtx c = load_hit(fr, wb.hits[c0 + j]);
+    const int SPP = max(u.spp, 1);
+    const int seed = (int)((uint32_t)u.frameIndex * (uint32_t)SPP + (uint32_t)s);
+    Work w;
+    (void)oneBounceGIBVH<GenGiTracer, false>(tr, c.F, c.hp, c.hn, u.frameIndex, seed, w);
     for (int k = 0; k < 6; ++k)
-        if (!(tr.shadowMask & (1u << k))) wb.sh2O[(uint32_t)(s * 6 + k) * wb.CH + j] = make_float4(0, 0, 0, -1.0f);
+        if (!(tr.shadowMask & (1u << k))) wb.sh2O[(uint32_t)k * (wb.CH * (uint32_t)wb.SPP) + pos] = make_float4(0, 0, 0, -1.0f);
 }
 
 // ---- stage: combine (thread = hit) ---------------------------------------------------------------
@@ -471,11 +534,15 @@ __global__ __launch_bounds__(256) void k_combine(const DevFrame *__restrict__ fr
 }
 
 template <class Src, bool ANY>
-void launch_trace(hipStream_t st, int blocks, int depth, const DevFrame *fr, Src src, uint32_t *head, uint32_t *tally) {
-    dim3 g((unsigned)blocks), b(256);
-    if (depth <= 16) hipLaunchKernelGGL((k_trace<Src, ANY, 16>), g, b, 0, st, fr, src, head, tally);
-    else if (depth <= 24) hipLaunchKernelGGL((k_trace<Src, ANY, 24>), g, b, 0, st, fr, src, head, tally);
-    else hipLaunchKernelGGL((k_trace<Src, ANY, 32>), g, b, 0, st, fr, src, head, tally);
+void launch_trace(hipStream_t st, int cus, int depth, const DevFrame *fr, Src src, uint32_t *head, uint32_t *tally, TraceTune tune) {
+    // resident 256-thread blocks per CU: LDS = 256 * STACK * entry bytes per block, capped at 8 (32 waves / CU)
+    const int entry = ANY ? 4 : 8;
+    const int stack = depth <= 16 ? 16 : (depth <= 24 ? 24 : 32);
+    const int perCU = std::max(1, std::min(8, (160 * 1024) / (256 * stack * entry)));
+    dim3 g((unsigned)(cus * perCU)), b(256);
+    if (stack == 16) hipLaunchKernelGGL((k_trace<Src, ANY, 16>), g, b, 0, st, fr, src, head, tally, tune);
+    else if (stack == 24) hipLaunchKernelGGL((k_trace<Src, ANY, 24>), g, b, 0, st, fr, src, head, tally, tune);
+    else hipLaunchKernelGGL((k_trace<Src, ANY, 32>), g, b, 0, st, fr, src, head, tally, tune);
 }
 
 }  // namespace
@@ -485,6 +552,7 @@ struct RtWave {
     std::string err;
     int cus = 256;
     size_t budgetBytes = (size_t)8 << 30;   // ray-queue budget per context; 288 GB of HBM make this cheap
+    TraceTune tune{32, 16, 2048};
     // allocations
     size_t slotsCap = 0;      // per-frame arrays sized for this many pixel slots
     size_t chunkBytes = 0;    // bytes of the per-chunk arena
@@ -496,6 +564,9 @@ RtWave *rt_wave_create(int cus) {
     RtWave *w = new RtWave();
     w->cus = cus > 0 ? cus : 256;
     if (const char *e = getenv("RT_QUEUE_BUDGET_MB")) w->budgetBytes = (size_t)atoll(e) << 20;
+    if (const char *e = getenv("RT_REFILL_MIN")) w->tune.refillMin = std::max(1, std::min(64, atoi(e)));
+    if (const char *e = getenv("RT_CHUNK")) w->tune.chunk = std::max(64, std::min(1 << 20, atoi(e)));
+    if (const char *e = getenv("RT_MIN_SEARCH")) w->tune.minSearch = std::max(0, std::min(64, atoi(e)));
     return w;
 }
 void rt_wave_destroy(RtWave *w) {
@@ -525,7 +596,7 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
     const int A = (u.enableAO == 1) ? std::max(u.aoSamples, 0) : 0;
     const int S1 = A + 6 * SPP, S2 = 6 * SPP;
 
-    if (!w->counts) { W_TRY(hipMalloc(&w->counts, 64 * sizeof(uint32_t))); W_TRY(hipMalloc(&w->heads, 4096 * sizeof(uint32_t))); }
+    if (!w->counts) { W_TRY(hipMalloc(&w->counts, (64 + 4096) * sizeof(uint32_t))); W_TRY(hipMalloc(&w->heads, 4096 * sizeof(uint32_t))); }
     // per-frame arena: cand, primT, primTri, hits
     if (w->slotsCap < nSlots) {
         if (w->frameArena) (void)hipFree(w->frameArena);
@@ -534,11 +605,11 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
         w->slotsCap = nSlots;
     }
     // chunk capacity from the budget
-    const size_t perHit = (size_t)(S1 + SPP + S2) * 32 + (size_t)S1 + (size_t)SPP * 8 + (size_t)S2;
+    const size_t perHit = (size_t)(S1 + SPP + S2) * 32 + (size_t)S1 + (size_t)SPP * 12 + (size_t)S2;
     size_t CH = std::min(nSlots, std::max<size_t>(w->budgetBytes / perHit, 4096));
     CH = align_up(CH, 256);
     const size_t need = align_up(CH * (size_t)S1 * 32, 256) + align_up(CH * (size_t)S1, 256) + align_up(CH * (size_t)SPP * 32, 256) +
-                        align_up(CH * (size_t)SPP * 8, 256) + align_up(CH * (size_t)S2 * 32, 256) + align_up(CH * (size_t)S2, 256) + 4096;
+                        align_up(CH * (size_t)SPP * 8, 256) + align_up(CH * (size_t)S2 * 32, 256) + align_up(CH * (size_t)S2, 256) + align_up(CH * (size_t)SPP * 4, 256) + 4096;
     if (w->chunkBytes < need) {
         if (w->chunkArena) (void)hipFree(w->chunkArena);
         w->chunkArena = nullptr;
@@ -561,15 +632,17 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
         wb.giT = (float *)take(CH * (size_t)SPP * 4); wb.giTri = (int *)take(CH * (size_t)SPP * 4);
         wb.sh2O = (float4 *)take(CH * (size_t)S2 * 16); wb.sh2D = (float4 *)take(CH * (size_t)S2 * 16);
         wb.occ2 = (uint8_t *)take(CH * (size_t)S2);
+        wb.giPos = (int *)take(CH * (size_t)SPP * 4);
     }
     wb.counts = w->counts; wb.heads = w->heads;
     wb.CH = (uint32_t)CH; wb.A = A; wb.SPP = SPP;
     const int nChunks = (int)((nSlots + CH - 1) / CH);
-    if (1 + nChunks * 3 > 4096) { w->err = "too many chunks for the cursor table; raise RT_QUEUE_BUDGET_MB"; return RT_ERR_UNSUPPORTED; }
+    if (nChunks > 1000) { w->err = "too many chunks for the cursor table; raise RT_QUEUE_BUDGET_MB"; return RT_ERR_UNSUPPORTED; }
 
-    W_TRY(hipMemsetAsync(w->counts, 0, 64 * sizeof(uint32_t), st));
+    W_TRY(hipMemsetAsync(w->counts, 0, (size_t)(64 + nChunks) * sizeof(uint32_t), st));
     W_TRY(hipMemsetAsync(w->heads, 0, (size_t)(1 + nChunks * 3) * sizeof(uint32_t), st));
-    const int traceBlocks = w->cus * 5;
+    const int traceBlocks = w->cus;
+    const TraceTune tune = w->tune;
     const unsigned tiles = (unsigned)std::max(host.g.nLocalTiles, 0);
     if (tiles == 0) return RT_OK;
 
@@ -580,7 +653,7 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
     rt_stage_begin(ctx, ST_TRACE_PRIMARY);
     PrimarySrc ps;
     ps.fr = dFrame; ps.cand = wb.cand; ps.count = &wb.counts[0]; ps.outT = wb.primT; ps.outTri = wb.primTri;
-    launch_trace<PrimarySrc, false>(st, traceBlocks, treeDepth, dFrame, ps, &wb.heads[0], &wb.counts[2]);
+    launch_trace<PrimarySrc, false>(st, traceBlocks, treeDepth, dFrame, ps, &wb.heads[0], &wb.counts[2], tune);
     rt_stage_end(ctx, ST_TRACE_PRIMARY, 1);
 
     rt_stage_begin(ctx, ST_POST_PRIMARY);
@@ -595,29 +668,29 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
         rt_stage_end(ctx, ST_GEN_DIRECT, 1);
 
         QueueSrc q1;
-        q1.o = wb.shO; q1.d = wb.shD; q1.hitCount = &wb.counts[1]; q1.c0 = c0; q1.CH = wb.CH; q1.slots = (uint32_t)S1;
+        q1.o = wb.shO; q1.d = wb.shD; q1.liveCount = &wb.counts[1]; q1.c0 = c0; q1.cap = wb.CH; q1.stride = wb.CH; q1.slots = (uint32_t)S1;
         q1.outT = nullptr; q1.outTri = nullptr; q1.outOcc = wb.occ1;
         rt_stage_begin(ctx, ST_TRACE_SHADOW);
-        launch_trace<QueueSrc, true>(st, traceBlocks, treeDepth, dFrame, q1, &wb.heads[1 + c * 3 + 0], &wb.counts[3]);
+        launch_trace<QueueSrc, true>(st, traceBlocks, treeDepth, dFrame, q1, &wb.heads[1 + c * 3 + 0], &wb.counts[3], tune);
         rt_stage_end(ctx, ST_TRACE_SHADOW, 1);
 
         if (u.enableGI == 1) {
             QueueSrc qg;
-            qg.o = wb.giO; qg.d = wb.giD; qg.hitCount = &wb.counts[1]; qg.c0 = c0; qg.CH = wb.CH; qg.slots = (uint32_t)SPP;
+            qg.o = wb.giO; qg.d = wb.giD; qg.liveCount = &wb.counts[1]; qg.c0 = c0; qg.cap = wb.CH; qg.stride = wb.CH; qg.slots = (uint32_t)SPP;
             qg.outT = wb.giT; qg.outTri = wb.giTri; qg.outOcc = nullptr;
             rt_stage_begin(ctx, ST_TRACE_GI);
-            launch_trace<QueueSrc, false>(st, traceBlocks, treeDepth, dFrame, qg, &wb.heads[1 + c * 3 + 1], &wb.counts[4]);
+            launch_trace<QueueSrc, false>(st, traceBlocks, treeDepth, dFrame, qg, &wb.heads[1 + c * 3 + 1], &wb.counts[4], tune);
             rt_stage_end(ctx, ST_TRACE_GI, 1);
 
             rt_stage_begin(ctx, ST_GEN_GI);
-            hipLaunchKernelGGL(k_gen_gi, dim3(gridHS), dim3(256), 0, st, dFrame, wb, c0);
+            hipLaunchKernelGGL(k_gen_gi, dim3(gridHS), dim3(256), 0, st, dFrame, wb, c0, &wb.counts[64 + c]);
             rt_stage_end(ctx, ST_GEN_GI, 1);
 
             QueueSrc q2;
-            q2.o = wb.sh2O; q2.d = wb.sh2D; q2.hitCount = &wb.counts[1]; q2.c0 = c0; q2.CH = wb.CH; q2.slots = (uint32_t)S2;
+            q2.o = wb.sh2O; q2.d = wb.sh2D; q2.liveCount = &wb.counts[64 + c]; q2.c0 = 0; q2.cap = wb.CH * (uint32_t)SPP; q2.stride = wb.CH * (uint32_t)SPP; q2.slots = 6u;
             q2.outT = nullptr; q2.outTri = nullptr; q2.outOcc = wb.occ2;
             rt_stage_begin(ctx, ST_TRACE_GI_SHADOW);
-            launch_trace<QueueSrc, true>(st, traceBlocks, treeDepth, dFrame, q2, &wb.heads[1 + c * 3 + 2], &wb.counts[5]);
+            launch_trace<QueueSrc, true>(st, traceBlocks, treeDepth, dFrame, q2, &wb.heads[1 + c * 3 + 2], &wb.counts[5], tune);
             rt_stage_end(ctx, ST_TRACE_GI_SHADOW, 1);
         }
         rt_stage_begin(ctx, ST_COMBINE);

@@ -1,0 +1,29 @@
+"""Render a few frames of the bench workload (no counting pass, no CPU baseline) -- the target of rocprofv3 runs."""
+import sys, argparse
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+import opengl_raytracing_amd as rt, scenes
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--frames", type=int, default=4)
+ap.add_argument("--camera", default="closeup")
+ap.add_argument("--pipeline", default="wave")
+ap.add_argument("--spp", type=int, default=4)
+ap.add_argument("--subdiv", type=int, default=6)
+ap.add_argument("--size", default="1920x1080")
+a = ap.parse_args()
+W, H = map(int, a.size.split("x"))
+nodes, tris = scenes.bunny_bvh(a.subdiv)
+faces = scenes.env_faces("Sky_01")
+p = rt.default_render_params(); p.sppPerFrame = a.spp
+cam = scenes.camera(a.camera, aspect=W / H)
+pipe = {"wave": rt.RT_PIPELINE_WAVEFRONT, "mega": rt.RT_PIPELINE_MEGAKERNEL}[a.pipeline]
+with rt.Renderer(pipeline=pipe) as r:
+    r.upload_bvh(nodes, tris); r.upload_env(faces); r.resize(W, H)
+    r.enable_stage_timing(True)
+    for f in range(a.frames):
+        r.render_frame(rt.frame_uniforms(p, cam, W, H, f, True, nodes.shape[0], tris.shape[0]))
+    r.synchronize()
+    st = r.stage_times()
+    print({k: round(v["ms"] / a.frames, 3) for k, v in st["stages"].items()})
