@@ -159,8 +159,10 @@ struct PrimarySrc {   // ray i = primary ray of candidate i
     const uint32_t *count;
     float *outT;
     int *outTri;
+    RT_DEV void prepare() {}
     RT_DEV uint32_t size() const { return *count; }
-    RT_DEV bool load(uint32_t i, V3 &ro, V3 &rd, float &tMax) const {
+    RT_DEV bool load(uint32_t i, V3 &ro, V3 &rd, float &tMax, uint32_t &token) const {
+        token = i;
         int px, py;
         slot_to_pixel(fr->g, cand[i], px, py);
         ro = ld3(fr->u.camPos);
@@ -178,19 +180,20 @@ struct QueueSrc {     // slot-major queue: ray r -> (slot = r / n, j = r % n) at
     float *outT;
     int *outTri;
     uint8_t *outOcc;
-    RT_DEV uint32_t live() const { uint32_t h = *liveCount; return h > c0 ? min(h - c0, cap) : 0u; }
-    RT_DEV uint32_t size() const { return live() * slots; }
-    RT_DEV uint32_t addr(uint32_t r) const { uint32_t n = live(); return (r / n) * stride + (r % n); }
-    RT_DEV bool load(uint32_t r, V3 &ro, V3 &rd, float &tMax) const {
+    uint32_t nLive;              // cached by prepare(): the count is final before this kernel starts
+    RT_DEV void prepare() { uint32_t h = *liveCount; nLive = h > c0 ? min(h - c0, cap) : 0u; }
+    RT_DEV uint32_t size() const { return nLive * slots; }
+    RT_DEV uint32_t addr(uint32_t r) const { return (r / nLive) * stride + (r % nLive); }
+    RT_DEV bool load(uint32_t r, V3 &ro, V3 &rd, float &tMax, uint32_t &token) const {
         uint32_t a = addr(r);
+        token = a;                       // results go to the same queue address: no second div/mod at retirement
         float4 oo = o[a];
-        if (oo.w < 0.0f) return false;   // slot not used by this sample
-        float4 dd = d[a];
+        float4 dd = d[a];                // both halves in flight together; dead slots (w < 0) are rare
         ro = f4xyz(oo); rd = f4xyz(dd); tMax = oo.w;
-        return true;
+        return oo.w >= 0.0f;
     }
-    RT_DEV void store_closest(uint32_t r, float t, int tri) const { uint32_t a = addr(r); outT[a] = t; outTri[a] = tri; }
-    RT_DEV void store_any(uint32_t r, bool occ) const { outOcc[addr(r)] = occ ? 1 : 0; }
+    RT_DEV void store_closest(uint32_t a, float t, int tri) const { outT[a] = t; outTri[a] = tri; }
+    RT_DEV void store_any(uint32_t a, bool occ) const { outOcc[a] = occ ? 1 : 0; }
 };
 
 // Tunables of the scheduler (overridable per context through RT_REFILL_MIN / RT_MIN_SEARCH for experiments).
@@ -200,12 +203,16 @@ template <bool ANY> struct StackOf { typedef StackEntry type; };          // clo
 template <> struct StackOf<true> { typedef uint32_t type; };              // any-hit: the pop-time cull never fires (tMax is constant)
 
 template <class Src, bool ANY, int STACK>
-__global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, Src src, uint32_t *head, uint32_t *tally, TraceTune tune) {
+__global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, const float4 *__restrict__ wnodes, const float4 *__restrict__ tris, Src src,
+                                                uint32_t *head, uint32_t *tally, TraceTune tune) {
     typedef typename StackOf<ANY>::type Entry;
     __shared__ Entry lds[4 * STACK * 64];
     Entry *stk = &lds[(threadIdx.x >> 6) * STACK * 64 + (threadIdx.x & 63)];
-    const DevScene &sc = fr->sc;
+    DevScene sc = fr->sc;   // private copy: node / triangle pointers stay in SGPRs instead of being re-read per step
+    sc.wnodes = wnodes;     // kernel-argument copies: known-global pointers (global_load, not flat_load)
+    sc.tris = tris;
     const float eps = fr->u.eps, inf = fr->u.inf;
+    src.prepare();
     const uint32_t n = src.size();
     const uint32_t lane = threadIdx.x & 63;
     // run length per reservation: ~8 runs per wave, so the tail stays balanced and the cursor stays cold
@@ -267,9 +274,11 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
                 if (rank < take) {
                     uint32_t my = runNext + rank;
                     float tMax;
-                    if (src.load(my, ro, rd, tMax)) {
+                    uint32_t token;
+                    const bool liveRay = src.load(my, ro, rd, tMax, token);
+                    rayId = token;
+                    if (liveRay) {
                         traced++;
-                        rayId = my;
                         rdInv = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
                         tBest = ANY ? tMax : inf;
                         triBest = -1;
@@ -278,8 +287,8 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
                         float tmin;
                         bool in = sc.hasBVH && slab(ro, rdInv, ld3(sc.rootMin), ld3(sc.rootMax), tmin) && !(tmin > tBest);
                         if (in) active = true;
-                        else if (ANY) src.store_any(my, false);
-                        else src.store_closest(my, inf, -1);
+                        else if (ANY) src.store_any(token, false);
+                        else src.store_closest(token, inf, -1);
                     }
                 }
             }
@@ -534,15 +543,15 @@ __global__ __launch_bounds__(256) void k_combine(const DevFrame *__restrict__ fr
 }
 
 template <class Src, bool ANY>
-void launch_trace(hipStream_t st, int cus, int depth, const DevFrame *fr, Src src, uint32_t *head, uint32_t *tally, TraceTune tune) {
+void launch_trace(hipStream_t st, int cus, int depth, const DevFrame *fr, const DevScene &hs, Src src, uint32_t *head, uint32_t *tally, TraceTune tune) {
     // resident 256-thread blocks per CU: LDS = 256 * STACK * entry bytes per block, capped at 8 (32 waves / CU)
     const int entry = ANY ? 4 : 8;
     const int stack = depth <= 16 ? 16 : (depth <= 24 ? 24 : 32);
     const int perCU = std::max(1, std::min(8, (160 * 1024) / (256 * stack * entry)));
     dim3 g((unsigned)(cus * perCU)), b(256);
-    if (stack == 16) hipLaunchKernelGGL((k_trace<Src, ANY, 16>), g, b, 0, st, fr, src, head, tally, tune);
-    else if (stack == 24) hipLaunchKernelGGL((k_trace<Src, ANY, 24>), g, b, 0, st, fr, src, head, tally, tune);
-    else hipLaunchKernelGGL((k_trace<Src, ANY, 32>), g, b, 0, st, fr, src, head, tally, tune);
+    if (stack == 16) hipLaunchKernelGGL((k_trace<Src, ANY, 16>), g, b, 0, st, fr, hs.wnodes, hs.tris, src, head, tally, tune);
+    else if (stack == 24) hipLaunchKernelGGL((k_trace<Src, ANY, 24>), g, b, 0, st, fr, hs.wnodes, hs.tris, src, head, tally, tune);
+    else hipLaunchKernelGGL((k_trace<Src, ANY, 32>), g, b, 0, st, fr, hs.wnodes, hs.tris, src, head, tally, tune);
 }
 
 }  // namespace
@@ -653,7 +662,7 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
     rt_stage_begin(ctx, ST_TRACE_PRIMARY);
     PrimarySrc ps;
     ps.fr = dFrame; ps.cand = wb.cand; ps.count = &wb.counts[0]; ps.outT = wb.primT; ps.outTri = wb.primTri;
-    launch_trace<PrimarySrc, false>(st, traceBlocks, treeDepth, dFrame, ps, &wb.heads[0], &wb.counts[2], tune);
+    launch_trace<PrimarySrc, false>(st, traceBlocks, treeDepth, dFrame, host.sc, ps, &wb.heads[0], &wb.counts[2], tune);
     rt_stage_end(ctx, ST_TRACE_PRIMARY, 1);
 
     rt_stage_begin(ctx, ST_POST_PRIMARY);
@@ -671,7 +680,7 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
         q1.o = wb.shO; q1.d = wb.shD; q1.liveCount = &wb.counts[1]; q1.c0 = c0; q1.cap = wb.CH; q1.stride = wb.CH; q1.slots = (uint32_t)S1;
         q1.outT = nullptr; q1.outTri = nullptr; q1.outOcc = wb.occ1;
         rt_stage_begin(ctx, ST_TRACE_SHADOW);
-        launch_trace<QueueSrc, true>(st, traceBlocks, treeDepth, dFrame, q1, &wb.heads[1 + c * 3 + 0], &wb.counts[3], tune);
+        launch_trace<QueueSrc, true>(st, traceBlocks, treeDepth, dFrame, host.sc, q1, &wb.heads[1 + c * 3 + 0], &wb.counts[3], tune);
         rt_stage_end(ctx, ST_TRACE_SHADOW, 1);
 
         if (u.enableGI == 1) {
@@ -679,7 +688,7 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
             qg.o = wb.giO; qg.d = wb.giD; qg.liveCount = &wb.counts[1]; qg.c0 = c0; qg.cap = wb.CH; qg.stride = wb.CH; qg.slots = (uint32_t)SPP;
             qg.outT = wb.giT; qg.outTri = wb.giTri; qg.outOcc = nullptr;
             rt_stage_begin(ctx, ST_TRACE_GI);
-            launch_trace<QueueSrc, false>(st, traceBlocks, treeDepth, dFrame, qg, &wb.heads[1 + c * 3 + 1], &wb.counts[4], tune);
+            launch_trace<QueueSrc, false>(st, traceBlocks, treeDepth, dFrame, host.sc, qg, &wb.heads[1 + c * 3 + 1], &wb.counts[4], tune);
             rt_stage_end(ctx, ST_TRACE_GI, 1);
 
             rt_stage_begin(ctx, ST_GEN_GI);
@@ -690,7 +699,7 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
             q2.o = wb.sh2O; q2.d = wb.sh2D; q2.liveCount = &wb.counts[64 + c]; q2.c0 = 0; q2.cap = wb.CH * (uint32_t)SPP; q2.stride = wb.CH * (uint32_t)SPP; q2.slots = 6u;
             q2.outT = nullptr; q2.outTri = nullptr; q2.outOcc = wb.occ2;
             rt_stage_begin(ctx, ST_TRACE_GI_SHADOW);
-            launch_trace<QueueSrc, true>(st, traceBlocks, treeDepth, dFrame, q2, &wb.heads[1 + c * 3 + 2], &wb.counts[5], tune);
+            launch_trace<QueueSrc, true>(st, traceBlocks, treeDepth, dFrame, host.sc, q2, &wb.heads[1 + c * 3 + 2], &wb.counts[5], tune);
             rt_stage_end(ctx, ST_TRACE_GI_SHADOW, 1);
         }
         rt_stage_begin(ctx, ST_COMBINE);

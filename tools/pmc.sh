@@ -1,33 +1,17 @@
 #!/bin/bash
-# usage: tools/pmc.sh <outdir-under-gpurun_out> -- <python args for tools/prof_frames.py>
-# Runs separate rocprofv3 --pmc passes (counters only; no trace domains) and prints per-kernel sums.
-set -e
-OUT=$GRAFT_REPO_ROOT/gpurun_out/$1; shift; shift
+# usage: tools/pmc.sh <outdir-under-gpurun_out> <set-ids e.g. "1 2"> -- <args for tools/prof_frames.py>
+OUT=$GRAFT_REPO_ROOT/gpurun_out/$1; SETS="$2"; shift; shift; shift
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-i=0
-for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_THREAD_CYCLES_VALU" \
-           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM_WR" \
-           "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum" \
-           "TA_BUSY_avr TA_FLAT_READ_WAVEFRONTS_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum" \
-           "FETCH_SIZE" "WRITE_SIZE"; do
-  i=$((i+1))
-  rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -- python3 $GRAFT_REPO_ROOT/tools/prof_frames.py "$@" > $OUT/p$i.log 2>&1 || { tail -5 $OUT/p$i.log; }
+declare -A S
+S[1]="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_THREAD_CYCLES_VALU"
+S[2]="SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM_WR"
+S[3]="TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum"
+S[4]="TA_BUSY_avr TA_FLAT_READ_WAVEFRONTS_sum"
+S[5]="FETCH_SIZE"
+S[6]="WRITE_SIZE"
+S[7]="TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_PENDING_STALL_CYCLES_sum"
+for i in $SETS; do
+  timeout -k 10 150 rocprofv3 --pmc ${S[$i]} --output-format csv -d $OUT/p$i -- python3 $GRAFT_REPO_ROOT/tools/prof_frames.py "$@" > $OUT/p$i.log 2>&1 || { echo "set $i failed"; tail -3 $OUT/p$i.log; }
 done
-python3 - "$OUT" <<'PY'
-import csv, glob, sys, collections
-out = sys.argv[1]
-agg = collections.defaultdict(lambda: collections.defaultdict(float)); calls = collections.Counter()
-for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
-    seen = set()
-    for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0][-60:]
-        agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
-        key = (f, r["Dispatch_Id"])
-        if key not in seen:
-            seen.add(key)
-for k, d in agg.items():
-    print(k)
-    for c, v in sorted(d.items()):
-        print(f"   {c:40s} {v:.4g}")
-PY
+python3 $GRAFT_REPO_ROOT/tools/pmc_sum.py $OUT

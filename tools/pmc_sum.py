@@ -1,0 +1,18 @@
+import csv, glob, sys, collections, re
+out = sys.argv[1]
+agg = collections.defaultdict(lambda: collections.defaultdict(float))
+def short(name):
+    m = re.search(r'(k_\w+)(<[^>]*>)?', name)
+    return (m.group(1) + (m.group(2) or '')) if m else None
+for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = short(r["Kernel_Name"])
+        if k: agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+for k, d in sorted(agg.items()):
+    print(k)
+    print('   ' + '  '.join(f"{c}={v:.3g}" for c, v in sorted(d.items())))
+    g = d.get
+    if g("SQ_ACTIVE_INST_VALU") and g("SQ_THREAD_CYCLES_VALU"): print(f"   lane_util={g('SQ_THREAD_CYCLES_VALU')/(g('SQ_INSTS_VALU') or 1)/64:.2f}", end='')
+    if g("SQ_WAVE_CYCLES") and g("SQ_WAIT_ANY"): print(f"  wait_frac={g('SQ_WAIT_ANY')/g('SQ_WAVE_CYCLES'):.2f} issue_frac={g('SQ_ACTIVE_INST_ANY',0)/g('SQ_WAVE_CYCLES'):.2f}", end='')
+    if g("TCP_TOTAL_CACHE_ACCESSES_sum"): print(f"  L1hit={1-g('TCP_TCC_READ_REQ_sum',0)/g('TCP_TOTAL_CACHE_ACCESSES_sum'):.2f} L2hit={g('TCC_HIT_sum',0)/max(g('TCC_HIT_sum',0)+g('TCC_MISS_sum',0),1):.2f}", end='')
+    print()
