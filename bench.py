@@ -52,13 +52,6 @@ def usable_cores():
     return n
 
 
-class _DevArray:
-    """Wrap a raw device pointer for torch.as_tensor via the CUDA array interface (no copy)."""
-
-    def __init__(self, ptr, nbytes):
-        self.__cuda_array_interface__ = {"shape": (nbytes // 2,), "typestr": "<i2", "data": (ptr, False), "version": 2}
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -73,6 +66,7 @@ def main():
     import torch
     import torch.distributed as dist
     import opengl_raytracing_amd as rt
+    from opengl_raytracing_amd.dist_gather import FrameGatherer
     import scenes
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -119,24 +113,12 @@ def main():
         rc.close()
 
         ren = make_renderer(False)
-        ext = torch.cuda.ExternalStream(ren.stream(), device=torch.device("cuda", local_rank))
-        gathered = frame_out = None
-        locals_ = None
-        if world > 1:
-            blk = ren.gather_block_bytes(rt.RT_TARGET_COLOR)
-            if rank == 0:
-                gathered = torch.empty((world, blk // 2), dtype=torch.int16, device="cuda")
-                frame_out = torch.empty((H, W, 4), dtype=torch.int16, device="cuda")
+        gatherer = FrameGatherer(ren) if world > 1 else None
 
         def step(f):
             ren.render_frame(uniforms(cam, f))
-            if world > 1:
-                ptr, nbytes = ren.local_target(rt.RT_TARGET_COLOR)
-                loc = torch.as_tensor(_DevArray(ptr, nbytes), device="cuda")
-                with torch.cuda.stream(ext):
-                    dist.gather(loc, list(gathered.unbind(0)) if rank == 0 else None, dst=0)
-                    if rank == 0:
-                        ren.assemble_gathered(rt.RT_TARGET_COLOR, gathered.data_ptr(), frame_out.data_ptr())
+            if gatherer:
+                gatherer.gather()      # one RCCL gather of COLOR0 to rank 0 + un-tiling kernel, on the renderer's stream
 
         for f in range(warmup):
             step(f)

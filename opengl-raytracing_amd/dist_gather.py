@@ -1,0 +1,68 @@
+"""Tile-parallel frame assembly across GPUs: one process per GPU, RCCL through torch.distributed.
+
+Each rank renders its 16x16 tiles into tile-major local targets (csrc/rt_frame.hpp).  Per frame the
+only exchange is ONE gather of the chosen target to rank 0 (RCCL lowers it to grouped send/recv
+over the point-to-point xGMI links, so the root's 7 inbound links run in parallel), followed by
+the un-tiling kernel on rank 0.  Nothing is reduced, so no all-reduce / ring is involved.
+torch is plumbing here: it wraps the library's device pointers (no copies) and orders the
+collective on the library's HIP stream.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+from . import RT_TARGET_COLOR, TARGET_CHANNELS
+
+
+class _DevBytes:
+    """Expose a raw device pointer to torch.as_tensor (CUDA array interface, zero copy)."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def wrap_device_bytes(ptr, nbytes, device):
+    return torch.as_tensor(_DevBytes(ptr, nbytes), device=device)
+
+
+class FrameGatherer:
+    def __init__(self, renderer, which=RT_TARGET_COLOR, group=None):
+        self.ren, self.which, self.group = renderer, which, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        self.stream = torch.cuda.ExternalStream(renderer.stream(), device=self.device)
+        self.block = renderer.gather_block_bytes(which)
+        ch = TARGET_CHANNELS[which]
+        self.gathered = self.frame = None
+        if self.rank == 0:
+            self.gathered = torch.empty((self.world, self.block), dtype=torch.uint8, device=self.device)   # bytes: RCCL has no int16
+            self.frame = torch.empty((renderer.height, renderer.width, ch * 2), dtype=torch.uint8, device=self.device)
+        self._wrapped = {}
+
+    def _local(self):
+        ptr, nbytes = self.ren.local_target(self.which)     # COLOR0 ping-pongs between two buffers
+        t = self._wrapped.get(ptr)
+        if t is None:
+            t = self._wrapped[ptr] = wrap_device_bytes(ptr, nbytes, self.device)
+        return t
+
+    def gather(self):
+        """Enqueue gather + assemble behind the frame just rendered (asynchronous; same stream as the kernels)."""
+        loc = self._local()
+        with torch.cuda.stream(self.stream):
+            if self.world > 1:
+                dist.gather(loc, list(self.gathered.unbind(0)) if self.rank == 0 else None, dst=0, group=self.group)
+            elif self.rank == 0:
+                self.gathered[0].copy_(loc, non_blocking=True)
+            if self.rank == 0:
+                self.ren.assemble_gathered(self.which, self.gathered.data_ptr(), self.frame.data_ptr())
+        return self.frame
+
+    def frame_halfs(self):
+        """Rank 0: the assembled frame as uint16 half bit patterns [H, W, C] on the host (synchronises)."""
+        self.ren.synchronize()
+        torch.cuda.synchronize()
+        ch = TARGET_CHANNELS[self.which]
+        return self.frame.cpu().numpy().view("<u2").reshape(self.ren.height, self.ren.width, ch)

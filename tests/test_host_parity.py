@@ -1,0 +1,139 @@
+"""Product host code (C++ in librt_mi355.so, reached through the C ABI) against the oracle's host
+restatement, on the CPU: scene build, camera / frame state, uniform marshalling, asset readers.
+Everything here is integer / exactly-rounded fp32 work, so the bar is bit equality."""
+import numpy as np
+import pytest
+
+import opengl_raytracing_amd as rt
+import scenes
+
+GOLDEN = scenes.ROOT / "tests" / "golden"
+
+
+def test_defaults_match(orc):
+    assert bytes(rt.default_render_params()) == bytes(orc.default_render_params())
+    assert bytes(rt.default_camera()) == bytes(orc.default_camera())
+    assert np.array_equal(rt.default_bvh_transform(), orc.default_bvh_transform())
+    p = rt.default_render_params()
+    assert (p.sppPerFrame, p.aoSamples, p.enableTAA, p.enableSVGF) == (1, 4, 1, 1)
+    assert abs(p.taaHistoryMinWeight - 0.85) < 1e-7 and abs(p.giScaleBVH - 0.20) < 1e-7 and abs(p.motionScale - 4.0) < 1e-7
+
+
+@pytest.mark.parametrize("yaw,pitch,fov,aspect", [(-90, -10, 60, 16 / 9), (-90, 0, 60, 1.0), (37.5, 22, 45, 4 / 3), (180, -89, 90, 2.0)])
+def test_camera_matrices_and_uniforms(orc, yaw, pitch, fov, aspect):
+    cam = rt.default_camera()
+    cam.yaw, cam.pitch, cam.fov, cam.aspect = yaw, pitch, fov, aspect
+    cam.pos[0] = 1.25
+    assert np.array_equal(rt.camera_view(cam), orc.camera_view(cam))
+    assert np.array_equal(rt.camera_proj(cam), orc.camera_proj(cam))
+    vp = rt.mat4_mul(rt.camera_proj(cam), rt.camera_view(cam))
+    assert np.array_equal(vp, orc.mat4_mul(orc.camera_proj(cam), orc.camera_view(cam)))
+    p = rt.default_render_params()
+    p.pointLightOrbitEnabled, p.pointLightYaw, p.pointLightPitch = 1, 33.0, 12.0
+    p.sunYaw, p.skyPitch = 200.0, 70.0
+    for frame, moved in ((0, False), (5, True), (1030, False)):
+        prev = vp.copy()
+        if moved:
+            prev[12] += 0.01
+        a = rt.make_uniforms(p, cam, rt.camera_view(cam), vp, prev, 640, 360, frame, moved, True, False, 10, 20, True)
+        b = orc.make_uniforms(p, cam, orc.camera_view(cam), vp, prev, 640, 360, frame, moved, True, False, 10, 20, True)
+        assert bytes(a) == bytes(b)
+        assert rt.camera_moved(vp, prev) == orc.camera_moved(vp, prev) == moved
+    u = rt.make_uniforms(p, cam, rt.camera_view(cam), vp, vp, 64, 64, 0, False, False, True, 0, 0, False)
+    assert u.spp == 1 and u.showMotion == 1 and u.useEnvMap == 0     # render.cpp:81,102
+
+
+def test_jitter_sequence(orc):
+    for i in list(range(40)) + [1023, 1024, 5000]:
+        assert np.array_equal(rt.generate_jitter(i), orc.generate_jitter(i))
+
+
+@pytest.mark.parametrize("kind", ["bunny2", "bunny4", "random300", "equal_centroids", "n9", "n1", "degenerate"])
+def test_bvh_build_matches_oracle(orc, kind):
+    rng = np.random.default_rng(9)
+    if kind.startswith("bunny"):
+        v, f = rt.meshgen.bunny_standin(int(kind[-1]))
+        a, b = rt.gather_triangles(v, f), orc.gather_triangles(v, f)
+        assert np.array_equal(a, b)
+        t = a
+    elif kind == "random300":
+        t = rng.normal(size=(300, 9)).astype(np.float32)
+    elif kind == "equal_centroids":   # nth_element ties: both sides run the same libstdc++ algorithm on the same keys
+        t = np.tile(rng.normal(size=(1, 9)).astype(np.float32), (64, 1))
+        t[::2, 0] += 1.0
+    elif kind == "n9":
+        t = rng.normal(size=(9, 9)).astype(np.float32)
+    elif kind == "n1":
+        t = rng.normal(size=(1, 9)).astype(np.float32)
+    else:
+        t = np.zeros((20, 9), np.float32)   # zero-area triangles at the origin
+    n1, t1 = rt.build_bvh(t)
+    n2, t2 = orc.build_bvh(t)
+    assert n1.shape == n2.shape and np.array_equal(n1.view(np.uint32), n2.view(np.uint32))
+    assert np.array_equal(t1.view(np.uint32), t2.view(np.uint32))
+
+
+def test_bvh_build_matches_committed_fixture():
+    d = np.load(GOLDEN / "bvh_build_320.npz")
+    n, t = rt.build_bvh(d["tris9"])
+    assert np.array_equal(n, d["nodes12"]) and np.array_equal(t, d["tris12"])
+    assert rt.build_bvh(np.zeros((0, 9), np.float32))[0].shape[0] == 0
+
+
+def test_gather_with_custom_matrix(orc):
+    rng = np.random.default_rng(2)
+    v = rng.normal(size=(50, 3)).astype(np.float32)
+    f = rng.integers(0, 50, size=90).astype(np.uint32)
+    m = rng.normal(size=16).astype(np.float32)
+    assert np.array_equal(rt.gather_triangles(v, f, m), orc.gather_triangles(v, f, m))
+    assert rt.gather_triangles(v, f[:4], m).shape[0] == 1      # trailing partial triple ignored (bvh.cpp:234)
+
+
+def test_obj_reader_round_trip(tmp_path):
+    v, f = rt.meshgen.bunny_standin(2)
+    path = tmp_path / "m.obj"
+    rt.meshgen.write_obj(path, v, f)
+    v2, f2 = rt.load_obj(path)
+    assert np.array_equal(v2, v) and np.array_equal(f2, f)
+    # quads (fan), negative indices, v/vt/vn forms, comments
+    (tmp_path / "q.obj").write_text("# c\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvn 0 0 1\nf 1/1/1 2/2/1 3//1 4\nf -4 -3 -2\n")
+    v3, f3 = rt.load_obj(tmp_path / "q.obj")
+    assert v3.shape == (4, 3) and list(f3) == [0, 1, 2, 0, 2, 3, 0, 1, 2]
+    with pytest.raises(rt.RtError):
+        rt.load_obj(tmp_path / "missing.obj")
+    (tmp_path / "bad.obj").write_text("v 0 0 0\nf 1 2 3\n")
+    with pytest.raises(rt.RtError):
+        rt.load_obj(tmp_path / "bad.obj")
+
+
+def test_png_reader_and_cross_slicing(orc, tmp_path):
+    from PIL import Image
+    img = rt.load_png(scenes.ASSETS / "Sky_16.png")
+    ref = np.asarray(Image.open(scenes.ASSETS / "Sky_16.png"))
+    assert img.shape == (1536, 2048, 3) and np.array_equal(img, ref)
+    assert np.array_equal(rt.cubemap_from_cross(img), orc.cubemap_from_cross(img))
+    rng = np.random.default_rng(4)
+    for mode, shape in (("RGBA", (9, 12, 4)), ("L", (6, 8)), ("RGB", (3, 4, 3))):
+        a = rng.integers(0, 256, size=shape, dtype=np.uint8)
+        Image.fromarray(a, mode).save(tmp_path / f"{mode}.png")
+        got = rt.load_png(tmp_path / f"{mode}.png")
+        assert np.array_equal(got.reshape(a.shape), a)
+    with pytest.raises(rt.RtError):
+        rt.cubemap_from_cross(np.zeros((9, 10, 3), np.uint8))        # not 4x3 (cubemap.cpp:47)
+    with pytest.raises(rt.RtError):
+        rt.load_png(tmp_path / "nope.png")
+    (tmp_path / "junk.png").write_bytes(b"not a png at all, really not" * 4)
+    with pytest.raises(rt.RtError):
+        rt.load_png(tmp_path / "junk.png")
+
+
+def test_tile_layout_mirror():
+    from opengl_raytracing_amd import tiles
+    rng = np.random.default_rng(1)
+    for (w, h, world) in ((200, 120, 1), (200, 120, 2), (1920, 1080, 8), (33, 17, 3)):
+        img = rng.integers(0, 65535, size=(h, w, 4)).astype(np.uint16)
+        blocks = [tiles.pack_local(img, r, world) for r in range(world)]
+        assert all(b.shape == blocks[0].shape for b in blocks)
+        assert np.array_equal(tiles.assemble(blocks, w, h), img)
+        masks = [tiles.owner_mask(w, h, r, world) for r in range(world)]
+        assert np.array_equal(sum(m.astype(int) for m in masks), np.ones((h, w), int))
