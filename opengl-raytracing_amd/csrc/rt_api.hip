@@ -26,10 +26,10 @@ struct RtContext {
     hipStream_t stream = nullptr;
     std::string err;
     // scene
-    float4 *dWNodes = nullptr, *dTris = nullptr;
+    float4 *dWNodes = nullptr, *dW4 = nullptr, *dTris = nullptr;
     uchar4 *dEnv = nullptr;
     int envSize = 0;
-    int nNodes = 0, nTris = 0, nInner = 0, rootRef = 0, treeDepth = 0;
+    int nNodes = 0, nTris = 0, nInner = 0, rootRef = 0, rootRef4 = 0, treeDepth = 0;
     float rootMin[3] = {0, 0, 0}, rootMax[3] = {0, 0, 0};
     // frame state
     FrameGeom g{};
@@ -157,10 +157,12 @@ __global__ __launch_bounds__(256) void k_debug_trace(DevScene sc, int kind, cons
 DevScene make_dev_scene(const RtContext *c) {
     DevScene s;
     s.wnodes = c->dWNodes;
+    s.w4 = c->dW4;
     s.tris = c->dTris;
     s.env = c->dEnv;
     s.envSize = c->envSize;
     s.rootRef = c->rootRef;
+    s.rootRef4 = c->rootRef4;
     s.hasBVH = (c->nNodes > 0 && c->nTris > 0) ? 1 : 0;
     std::memcpy(s.rootMin, c->rootMin, 12);
     std::memcpy(s.rootMax, c->rootMax, 12);
@@ -268,6 +270,7 @@ void rt_destroy(RtContext *c) {
     free_targets(c);
     if (c->wave) rt_wave_destroy(c->wave);
     if (c->dWNodes) (void)hipFree(c->dWNodes);
+    if (c->dW4) (void)hipFree(c->dW4);
     if (c->dTris) (void)hipFree(c->dTris);
     if (c->dEnv) (void)hipFree(c->dEnv);
     if (c->dFrame) (void)hipFree(c->dFrame);
@@ -285,8 +288,9 @@ int rt_upload_bvh(RtContext *c, const float *nodes12, int nNodes, const float *t
     (void)hipSetDevice(c->cfg.device);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (c->dWNodes) (void)hipFree(c->dWNodes);
+    if (c->dW4) (void)hipFree(c->dW4);
     if (c->dTris) (void)hipFree(c->dTris);
-    c->dWNodes = c->dTris = nullptr;
+    c->dWNodes = c->dW4 = c->dTris = nullptr;
     c->nNodes = c->nTris = c->nInner = 0;
     c->treeDepth = 0;
     if (nNodes == 0 || nTris == 0) return RT_OK;
@@ -338,8 +342,49 @@ int rt_upload_bvh(RtContext *c, const float *nodes12, int nNodes, const float *t
             if (nd[(size_t)n].count <= 0) { st.push_back({nd[(size_t)n].left, d + 1}); st.push_back({nd[(size_t)n].right, d + 1}); }
         }
     }
+    // 4-wide nodes for any-hit rays: every binary inner node at an even level absorbs its inner children, so one
+    // 128-byte record holds up to four grandchild boxes.  A child box is only skipped (never tested) when it is an
+    // intermediate node; by monotonicity of the slab arithmetic a grandchild that passes its own test also passes
+    // its parent's, so the set of triangles tested -- and hence every any-hit answer -- is unchanged.
+    std::vector<float> w4;
+    int rootRef4 = refOf(0);
+    if (nd[0].count <= 0) {
+        struct Job { int bin; size_t at; };   // fill node `at` (index into w4 / 32) from binary node `bin`
+        std::vector<Job> jobs;
+        w4.resize(32, 0.0f);
+        jobs.push_back({0, 0});
+        rootRef4 = 0;
+        while (!jobs.empty()) {
+            Job jb = jobs.back();
+            jobs.pop_back();
+            int kids[4], nk = 0;
+            for (int ch : {nd[(size_t)jb.bin].left, nd[(size_t)jb.bin].right}) {
+                if (nd[(size_t)ch].count > 0) kids[nk++] = ch;
+                else { kids[nk++] = nd[(size_t)ch].left; kids[nk++] = nd[(size_t)ch].right; }
+            }
+            for (int i = 0; i < 4; ++i) {
+                int ref = RT_NO_CHILD;
+                if (i < nk) {
+                    const float *b = nodes12 + (size_t)kids[i] * 12;
+                    if (nd[(size_t)kids[i]].count > 0) ref = refOf(kids[i]);
+                    else {
+                        ref = (int)(w4.size() / 32);
+                        w4.resize(w4.size() + 32, 0.0f);
+                        jobs.push_back({kids[i], (size_t)ref});
+                    }
+                    float *o = &w4[jb.at * 32 + (size_t)i * 8];
+                    o[0] = b[0]; o[1] = b[1]; o[2] = b[2];
+                    o[4] = b[4]; o[5] = b[5]; o[6] = b[6];
+                }
+                std::memcpy(&w4[jb.at * 32 + (size_t)i * 8 + 3], &ref, 4);
+            }
+        }
+    } else w4.resize(32, 0.0f);
     if (depth > 32) return fail(c, RT_ERR_UNSUPPORTED, "rt_upload_bvh: tree depth %d exceeds the 32-entry traversal stack", depth);
     HIP_TRY(c, hipMalloc(&c->dWNodes, wn.size() * sizeof(float)));
+    HIP_TRY(c, hipMalloc(&c->dW4, w4.size() * sizeof(float)));
+    HIP_TRY(c, hipMemcpy(c->dW4, w4.data(), w4.size() * sizeof(float), hipMemcpyHostToDevice));
+    c->rootRef4 = rootRef4;
     HIP_TRY(c, hipMalloc(&c->dTris, (size_t)nTris * 12 * sizeof(float)));
     HIP_TRY(c, hipMemcpy(c->dWNodes, wn.data(), wn.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->dTris, tris12, (size_t)nTris * 12 * sizeof(float), hipMemcpyHostToDevice));

@@ -22,12 +22,17 @@ namespace rtd {
 //   tris  : 3 x float4 per triangle  : [v0.xyz, -] [e1.xyz, -] [e2.xyz, -]      (bvh.cpp:187-204 order)
 //   child reference: >= 0 -> inner node index;  < 0 -> leaf, v = -ref-1, first = v >> 3, count = (v & 7) + 1
 //   env   : 6 faces of RGBA8 (GL face order), envSize^2 texels each
+//   w4    : 8 x float4 per 4-wide node (two binary levels collapsed; any-hit rays only, where visiting order is
+//           free): [min_i.xyz, ref_i] [max_i.xyz, -] for i = 0..3, ref == RT_NO_CHILD for an absent child
+#define RT_NO_CHILD 0x7fffffff
 struct DevScene {
     const float4 *wnodes;
+    const float4 *w4;
     const float4 *tris;
     const uchar4 *env;
     int envSize;
     int rootRef;
+    int rootRef4;
     int hasBVH;
     float rootMin[3], rootMax[3];
 };
@@ -379,7 +384,10 @@ RT_DEV DiskSample diskSample(const Frag &F, V3 hp, V3 N, int frame, int i, V2 ro
 enum { SEG_DIRECT = 0, SEG_GI_DIRECT = 1 };
 
 // directLightBVH (:405-460) over a tracer policy T:
-//   bool T::shadow(int seg, int k, V3 ro, V3 rd, float tMax)   k = 0..3 disk, 4 sun, 5 point
+//   bool T::shadow(int seg, int k, V3 ro, V3 rd, float tMax, bool matters)   k = 0..3 disk, 4 sun, 5 point
+// `matters` is false when the visibility cannot reach the output: the reference casts the disk-sample
+// ray even when geom == 0 (rt_lighting.glsl:437-438), but then Li = kLightCol*0*vis = 0 for either
+// answer.  A tracer may skip such a ray and return anything.
 template <class T>
 RT_DEV V3 directLightBVH(T &tr, const Frag &F, int seg, V3 hp, V3 hn, int frame, V3 Vdir) {
     const RtUniforms &u = *F.u;
@@ -393,7 +401,7 @@ RT_DEV V3 directLightBVH(T &tr, const Frag &F, int seg, V3 hp, V3 hn, int frame,
     V3 V = normalize(Vdir);
     for (int i = 0; i < 4; ++i) {   // SOFT_SHADOW_SAMPLES
         DiskSample s = diskSample(F, hp, N, frame, i, rot, lt, lb);
-        float vis = tr.shadow(seg, i, s.ro, s.rd, s.tMax) ? 0.0f : 1.0f;
+        float vis = tr.shadow(seg, i, s.ro, s.rd, s.tMax, s.geom != 0.0f) ? 0.0f : 1.0f;
         V3 Li = mk3(18.0f) * s.geom * vis;
         sum = sum + shadeLambertPhong(u.pi, N, V, s.L, Li, albedo, specStrength, gloss);
     }
@@ -410,7 +418,7 @@ RT_DEV V3 directLightBVH(T &tr, const Frag &F, int seg, V3 hp, V3 hn, int frame,
             float maxT = 1000.0f;
             float e = epsForDist(maxT);
             V3 origin = hp + N * e;
-            bool blocked = tr.shadow(seg, 4, origin, L, maxT - e);
+            bool blocked = tr.shadow(seg, 4, origin, L, maxT - e, true);
             if (!blocked) sun = shadeLambertPhong(u.pi, N, Vs, L, ld3(u.sunColor) * u.sunIntensity, albedo, specStrength, gloss);
         }
     }
@@ -429,7 +437,7 @@ RT_DEV V3 directLightBVH(T &tr, const Frag &F, int seg, V3 hp, V3 hn, int frame,
             if (ndl > 0.0f) {
                 float e = epsForDist(dist);
                 V3 origin = hp + L * e;
-                bool blocked = tr.shadow(seg, 5, origin, L, dist - e);
+                bool blocked = tr.shadow(seg, 5, origin, L, dist - e, true);
                 if (!blocked) {
                     V3 Li = ld3(u.pointLightColor) * (u.pointLightIntensity / fmaxr(dist2, 1e-4f));
                     pt = shadeLambertPhong(u.pi, N, Vp, L, Li, albedo, specStrength, gloss);

@@ -19,7 +19,8 @@ struct InlineTracer {
     float eps, inf;
     StackEntry *stk;
     Work *w;
-    __device__ __noinline__ bool shadow(int, int, V3 ro, V3 rd, float tMax) { return bvh_anyhit<COUNT>(*sc, ro, rd, eps, tMax, stk, *w); }
+    // the megakernel is the reference-shaped baseline: it traces every ray the reference casts, needed or not
+    __device__ __noinline__ bool shadow(int, int, V3 ro, V3 rd, float tMax, bool) { return bvh_anyhit<COUNT>(*sc, ro, rd, eps, tMax, stk, *w); }
     __device__ __noinline__ bool closest(V3 ro, V3 rd, float &t, int &tri) { return bvh_closest<COUNT>(*sc, ro, rd, eps, inf, stk, t, tri, *w); }
     RT_DEV int gi(V3 ro, V3 rd, V3 &hp, V3 &hn) {
         float t;

@@ -208,9 +208,9 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
     typedef typename StackOf<ANY>::type Entry;
     __shared__ Entry lds[4 * STACK * 64];
     Entry *stk = &lds[(threadIdx.x >> 6) * STACK * 64 + (threadIdx.x & 63)];
-    DevScene sc = fr->sc;   // private copy: node / triangle pointers stay in SGPRs instead of being re-read per step
-    sc.wnodes = wnodes;     // kernel-argument copies: known-global pointers (global_load, not flat_load)
-    sc.tris = tris;
+    DevScene sc = fr->sc;   // private copy: scene constants stay in SGPRs instead of being re-read per step
+    sc.tris = tris;         // kernel-argument copies: known-global pointers (global_load, not flat_load)
+    const float4 *__restrict__ nodes = wnodes;   // 2-wide records for closest-hit, 4-wide records for any-hit
     const float eps = fr->u.eps, inf = fr->u.inf;
     src.prepare();
     const uint32_t n = src.size();
@@ -234,12 +234,12 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
         bool found = false;
         while (sp > 0) {
             sp--;
-            if (ANY) {
-                ref = (int)((const uint32_t *)stk)[sp * 64 * (sizeof(Entry) / 4)];
+            if constexpr (ANY) {
+                ref = (int)stk[sp * 64];
                 found = true;
                 break;
             } else {
-                StackEntry e = ((const StackEntry *)stk)[sp * 64];
+                StackEntry e = stk[sp * 64];
                 if (u2f(e.y) > tBest) continue;   // rt_bvh.glsl:208 cull
                 ref = (int)e.x;
                 found = true;
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
                         tBest = ANY ? tMax : inf;
                         triBest = -1;
                         sp = 0;
-                        ref = sc.rootRef;
+                        ref = ANY ? sc.rootRef4 : sc.rootRef;
                         float tmin;
                         bool in = sc.hasBVH && slab(ro, rdInv, ld3(sc.rootMin), ld3(sc.rootMax), tmin) && !(tmin > tBest);
                         if (in) active = true;
@@ -306,27 +306,42 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
             if (sm == 0ull) break;
             if (__popcll(sm) < tune.minSearch && __ballot(active && ref < 0) != 0ull) break;   // keep the leaf phase dense
             if (searching) {
-                const float4 *nd = sc.wnodes + (size_t)ref * 4;
-                float4 a = nd[0], b = nd[1], c = nd[2], d = nd[3];
-                float tL, tR;
-                bool hitL = slab(ro, rdInv, f4xyz(a), f4xyz(b), tL) && tL <= tBest;
-                bool hitR = slab(ro, rdInv, f4xyz(c), f4xyz(d), tR) && tR <= tBest;
-                int refL = (int)f2u(a.w), refR = (int)f2u(b.w);
-                if (hitL && hitR) {
-                    bool leftFirst = tL < tR;
-                    if (ANY) {
-                        ((uint32_t *)stk)[sp * 64 * (sizeof(Entry) / 4)] = (uint32_t)(leftFirst ? refR : refL);
-                    } else {
+                if constexpr (ANY) {
+                    // 4-wide node: up to four grandchild boxes per 128-byte record, order irrelevant for any-hit
+                    const float4 *nd = nodes + (size_t)ref * 8;
+                    float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3], q4 = nd[4], q5 = nd[5], q6 = nd[6], q7 = nd[7];
+                    int r0 = (int)f2u(q0.w), r1 = (int)f2u(q2.w), r2 = (int)f2u(q4.w), r3 = (int)f2u(q6.w);
+                    float t0, t1, t2, t3;
+                    bool h0 = slab(ro, rdInv, f4xyz(q0), f4xyz(q1), t0) && t0 <= tBest;
+                    bool h1 = slab(ro, rdInv, f4xyz(q2), f4xyz(q3), t1) && t1 <= tBest;
+                    bool h2 = r2 != RT_NO_CHILD && slab(ro, rdInv, f4xyz(q4), f4xyz(q5), t2) && t2 <= tBest;
+                    bool h3 = r3 != RT_NO_CHILD && slab(ro, rdInv, f4xyz(q6), f4xyz(q7), t3) && t3 <= tBest;
+                    int nxt = RT_NO_CHILD;
+                    if (h0) nxt = r0;
+                    if (h1) { if (nxt == RT_NO_CHILD) nxt = r1; else { stk[sp * 64] = (uint32_t)r1; sp++; } }
+                    if (h2) { if (nxt == RT_NO_CHILD) nxt = r2; else { stk[sp * 64] = (uint32_t)r2; sp++; } }
+                    if (h3) { if (nxt == RT_NO_CHILD) nxt = r3; else { stk[sp * 64] = (uint32_t)r3; sp++; } }
+                    if (nxt == RT_NO_CHILD) pop_or_finish();
+                    else ref = nxt;
+                } else {
+                    const float4 *nd = nodes + (size_t)ref * 4;
+                    float4 a = nd[0], b = nd[1], c = nd[2], d = nd[3];
+                    float tL, tR;
+                    bool hitL = slab(ro, rdInv, f4xyz(a), f4xyz(b), tL) && tL <= tBest;
+                    bool hitR = slab(ro, rdInv, f4xyz(c), f4xyz(d), tR) && tR <= tBest;
+                    int refL = (int)f2u(a.w), refR = (int)f2u(b.w);
+                    if (hitL && hitR) {
+                        bool leftFirst = tL < tR;
                         StackEntry e;
                         e.x = (uint32_t)(leftFirst ? refR : refL);
                         e.y = f2u(leftFirst ? tR : tL);
-                        ((StackEntry *)stk)[sp * 64] = e;
-                    }
-                    sp++;
-                    ref = leftFirst ? refL : refR;
-                } else if (hitL || hitR) {
-                    ref = hitL ? refL : refR;
-                } else pop_or_finish();
+                        stk[sp * 64] = e;
+                        sp++;
+                        ref = leftFirst ? refL : refR;
+                    } else if (hitL || hitR) {
+                        ref = hitL ? refL : refR;
+                    } else pop_or_finish();
+                }
             }
         }
         // ---- phase 2: leaves
@@ -390,11 +405,12 @@ struct GenDirectTracer {   // records first-generation rays of (hit j, sample s)
     int s;
     uint32_t shadowMask;
     bool giCast;
-    RT_DEV bool shadow(int, int k, V3 ro, V3 rd, float tMax) {
+    RT_DEV bool shadow(int, int k, V3 ro, V3 rd, float tMax, bool matters) {
         uint32_t a = (uint32_t)(wb.A + s * 6 + k) * wb.CH + j;
+        shadowMask |= 1u << k;
+        if (!matters) { wb.shO[a] = make_float4(0, 0, 0, -1.0f); return false; }   // dead ray: its answer is multiplied by zero
         wb.shO[a] = mkf4(ro, fmaxr(tMax, 0.0f));
         wb.shD[a] = mkf4(rd, 0.0f);
-        shadowMask |= 1u << k;
         return false;
     }
     RT_DEV int gi(V3 ro, V3 rd, V3 &, V3 &) {
@@ -419,12 +435,13 @@ struct GenGiTracer {       // reads the bounce result, records the shadow rays a
     int s;
     uint32_t pos;
     uint32_t shadowMask;
-    RT_DEV bool shadow(int seg, int k, V3 ro, V3 rd, float tMax) {
+    RT_DEV bool shadow(int seg, int k, V3 ro, V3 rd, float tMax, bool matters) {
         if (seg != SEG_GI_DIRECT) return false;
         uint32_t a = (uint32_t)k * (wb.CH * (uint32_t)wb.SPP) + pos;
+        shadowMask |= 1u << k;
+        if (!matters) { wb.sh2O[a] = make_float4(0, 0, 0, -1.0f); return false; }
         wb.sh2O[a] = mkf4(ro, fmaxr(tMax, 0.0f));
         wb.sh2D[a] = mkf4(rd, 0.0f);
-        shadowMask |= 1u << k;
         return false;
     }
     RT_DEV int gi(V3 ro, V3 rd, V3 &hp, V3 &hn) {
@@ -442,7 +459,8 @@ struct CombineTracer {     // reads everything
     const DevScene *sc;
     uint32_t j;
     int s;
-    RT_DEV bool shadow(int seg, int k, V3, V3, float) {
+    RT_DEV bool shadow(int seg, int k, V3, V3, float, bool matters) {
+        if (!matters) return false;
         if (seg == SEG_DIRECT) return wb.occ1[(uint32_t)(wb.A + s * 6 + k) * wb.CH + j] != 0;
         return wb.occ2[(uint32_t)k * (wb.CH * (uint32_t)wb.SPP) + (uint32_t)wb.giPos[(uint32_t)s * wb.CH + j]] != 0;
     }
@@ -544,14 +562,17 @@ __global__ __launch_bounds__(256) void k_combine(const DevFrame *__restrict__ fr
 
 template <class Src, bool ANY>
 void launch_trace(hipStream_t st, int cus, int depth, const DevFrame *fr, const DevScene &hs, Src src, uint32_t *head, uint32_t *tally, TraceTune tune) {
-    // resident 256-thread blocks per CU: LDS = 256 * STACK * entry bytes per block, capped at 8 (32 waves / CU)
-    const int entry = ANY ? 4 : 8;
-    const int stack = depth <= 16 ? 16 : (depth <= 24 ? 24 : 32);
-    const int perCU = std::max(1, std::min(8, (160 * 1024) / (256 * stack * entry)));
+    // Stack entries: closest-hit defers one sibling per binary level (8 B each); any-hit walks 4-wide nodes and can
+    // defer three per two levels (4 B each).  Resident 256-thread blocks per CU follow from the LDS footprint.
+    const int need = ANY ? 3 * ((depth + 1) / 2) : depth;
+    const int s0 = ANY ? 24 : 16, s1 = ANY ? 36 : 24, s2 = ANY ? 48 : 32;
+    const int stack = need <= s0 ? s0 : (need <= s1 ? s1 : s2);
+    const int perCU = std::max(1, std::min(8, (160 * 1024) / (256 * stack * (ANY ? 4 : 8))));
+    const float4 *nodes = ANY ? hs.w4 : hs.wnodes;
     dim3 g((unsigned)(cus * perCU)), b(256);
-    if (stack == 16) hipLaunchKernelGGL((k_trace<Src, ANY, 16>), g, b, 0, st, fr, hs.wnodes, hs.tris, src, head, tally, tune);
-    else if (stack == 24) hipLaunchKernelGGL((k_trace<Src, ANY, 24>), g, b, 0, st, fr, hs.wnodes, hs.tris, src, head, tally, tune);
-    else hipLaunchKernelGGL((k_trace<Src, ANY, 32>), g, b, 0, st, fr, hs.wnodes, hs.tris, src, head, tally, tune);
+    if (stack == s0) hipLaunchKernelGGL((k_trace<Src, ANY, (ANY ? 24 : 16)>), g, b, 0, st, fr, nodes, hs.tris, src, head, tally, tune);
+    else if (stack == s1) hipLaunchKernelGGL((k_trace<Src, ANY, (ANY ? 36 : 24)>), g, b, 0, st, fr, nodes, hs.tris, src, head, tally, tune);
+    else hipLaunchKernelGGL((k_trace<Src, ANY, (ANY ? 48 : 32)>), g, b, 0, st, fr, nodes, hs.tris, src, head, tally, tune);
 }
 
 }  // namespace
