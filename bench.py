@@ -138,6 +138,7 @@ def main():
             dist.barrier()
         dt = time.perf_counter() - t0
         stages = ren.stage_times() if timed_stage else None
+        traced = ren.traced_rays()
         ren.close()
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         cc = torch.tensor(list(cnt.to_dict().values()), dtype=torch.int64, device="cuda")
@@ -145,7 +146,13 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dist.all_reduce(cc, op=dist.ReduceOp.SUM)
         total = rt.RtCounters(*[int(v) for v in cc.tolist()])
-        return {"seconds": float(tt.item()), "counters": total, "local_counters": cnt, "stages": stages}
+        tr = torch.tensor([traced.rays, traced.frames], dtype=torch.int64, device="cuda")
+        if world > 1:
+            dist.all_reduce(tr, op=dist.ReduceOp.SUM)
+        frames_all = max(int(tr[1].item()) // world, 1)
+        traced_per_frame = int(tr[0].item()) * steps // frames_all // steps if traced.frames else 0
+        return {"seconds": float(tt.item()), "counters": total, "local_counters": cnt, "stages": stages,
+                "traced_per_frame": traced_per_frame}
 
     closeup = run_camera(scenes.camera("closeup"), args.steps, args.warmup)
     res = closeup
@@ -180,7 +187,11 @@ def main():
                                "4 spp, GI 1 bounce + AO 4, Sky_01 env, close-up camera (-2,1.5,1.0)" % (args.subdiv, tris.shape[0]),
                    "pipeline": args.pipeline, "tiles": "16x16 round-robin over ranks" if world > 1 else "single GPU",
                    "rays_per_frame": rays // args.steps, "msample_per_s": npix * SPP * args.steps / res["seconds"] / 1e6,
-                   "hit_pixels": res["counters"].hitPixels // args.steps},
+                   "hit_pixels": res["counters"].hitPixels // args.steps,
+                   "rays_traversed_per_frame": res["traced_per_frame"],
+                   "ray_accounting": "value counts the reference shader's traceBVH/traceBVHShadow calls (SURVEY 8d); "
+                                     "identical rays (SPP copies of the primary and AO rays) are traversed once and disk-light "
+                                     "shadow rays of exactly zero weight are not traversed: rays_traversed_per_frame"},
         "roofline": roofline,
     }
     if st:

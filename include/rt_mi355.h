@@ -187,6 +187,12 @@ int rt_stream(RtContext *ctx, void **hipStream);
 int rt_get_counters(RtContext *ctx, RtCounters *out);   /* needs countWork; totals since rt_reset_counters */
 int rt_reset_counters(RtContext *ctx);
 
+/* Rays the wavefront pipeline actually traversed since the last reset (identical rays of the reference -- the SPP
+ * copies of a primary ray, the per-sample copies of the AO rays -- are traced once; disk-light shadow rays whose
+ * weight is exactly zero are not traced at all).  RtCounters keeps counting in the reference's units. */
+typedef struct RtTracedRays { uint64_t candidatePixels, hitPixels, primary, shadow, bounce, bounceShadow, frames; } RtTracedRays;
+int rt_get_traced_rays(RtContext *ctx, RtTracedRays *out, int reset);
+
 /* Device timing of the dominant kernel(s): HIP events recorded on the context's stream around each
  * stage of every frame since the last reset.  stage names: rt_stage_name(i). */
 #define RT_MAX_STAGES 12

@@ -121,6 +121,14 @@ class RtStageTimes(_Struct):
     _fields_ = [("nStages", i32), ("frames", i32), ("ms", C.c_double * RT_MAX_STAGES), ("launches", C.c_uint64 * RT_MAX_STAGES)]
 
 
+class RtTracedRays(_Struct):
+    _fields_ = [(n, C.c_uint64) for n in ("candidatePixels", "hitPixels", "primary", "shadow", "bounce", "bounceShadow", "frames")]
+
+    @property
+    def rays(self):
+        return self.primary + self.shadow + self.bounce + self.bounceShadow
+
+
 class RtError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"rt_mi355 error {code}: {msg}")
@@ -152,6 +160,7 @@ SIGNATURES = {
     "rt_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "rt_get_counters": (C.c_int, [C.c_void_p, C.POINTER(RtCounters)]),
     "rt_reset_counters": (C.c_int, [C.c_void_p]),
+    "rt_get_traced_rays": (C.c_int, [C.c_void_p, C.POINTER(RtTracedRays), C.c_int]),
     "rt_enable_stage_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "rt_get_stage_times": (C.c_int, [C.c_void_p, C.POINTER(RtStageTimes)]),
     "rt_stage_name": (C.c_char_p, [C.c_int]),
@@ -437,6 +446,11 @@ class Renderer:
 
     def reset_counters(self):
         self._check(lib().rt_reset_counters(self._h))
+
+    def traced_rays(self, reset=False) -> RtTracedRays:
+        t = RtTracedRays()
+        self._check(lib().rt_get_traced_rays(self._h, C.byref(t), int(reset)))
+        return t
 
     def enable_stage_timing(self, on=True):
         self._check(lib().rt_enable_stage_timing(self._h, int(on)))

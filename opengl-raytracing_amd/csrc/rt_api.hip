@@ -596,6 +596,17 @@ int rt_reset_counters(RtContext *c) {
     return RT_OK;
 }
 
+int rt_get_traced_rays(RtContext *c, RtTracedRays *out, int reset) {
+    if (!c || !out) return RT_ERR_INVALID;
+    (void)hipSetDevice(c->cfg.device);
+    unsigned long long v[8];
+    int rc = rt_wave_traced(c->wave, c->stream, v, reset != 0);
+    if (rc != RT_OK) return fail(c, rc, "rt_get_traced_rays: %s", rt_wave_error(c->wave));
+    out->candidatePixels = v[0]; out->hitPixels = v[1]; out->primary = v[2]; out->shadow = v[3]; out->bounce = v[4];
+    out->bounceShadow = v[5]; out->frames = v[6];
+    return RT_OK;
+}
+
 int rt_enable_stage_timing(RtContext *c, int enable) {
     if (!c) return RT_ERR_INVALID;
     (void)hipSetDevice(c->cfg.device);

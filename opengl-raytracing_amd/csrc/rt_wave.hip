@@ -560,6 +560,13 @@ __global__ __launch_bounds__(256) void k_combine(const DevFrame *__restrict__ fr
     finish_pixel(fr, tg, (int)c.slot, c.px, c.py, frameSum, motionOut, mk4(c.hp.x, c.hp.y, c.hp.z, 1.0f), mk4(nn.x, nn.y, nn.z, 0.0f));
 }
 
+__global__ void k_accum_tally(const uint32_t *counts, unsigned long long *acc) {
+    // acc: [0] candidates [1] hits [2] primary rays traced [3] shadow [4] bounce [5] bounce-shadow [6] frames
+    int i = threadIdx.x;
+    if (i < 6) acc[i] += counts[i];
+    if (i == 6) acc[6] += 1ull;
+}
+
 template <class Src, bool ANY>
 void launch_trace(hipStream_t st, int cus, int depth, const DevFrame *fr, const DevScene &hs, Src src, uint32_t *head, uint32_t *tally, TraceTune tune) {
     // Stack entries: closest-hit defers one sibling per binary level (8 B each); any-hit walks 4-wide nodes and can
@@ -588,6 +595,7 @@ struct RtWave {
     size_t chunkBytes = 0;    // bytes of the per-chunk arena
     void *frameArena = nullptr, *chunkArena = nullptr;
     uint32_t *counts = nullptr, *heads = nullptr;
+    unsigned long long *acc = nullptr;   // traced-ray tallies accumulated over frames
 };
 
 RtWave *rt_wave_create(int cus) {
@@ -605,6 +613,7 @@ void rt_wave_destroy(RtWave *w) {
     if (w->chunkArena) (void)hipFree(w->chunkArena);
     if (w->counts) (void)hipFree(w->counts);
     if (w->heads) (void)hipFree(w->heads);
+    if (w->acc) (void)hipFree(w->acc);
     delete w;
 }
 const char *rt_wave_error(const RtWave *w) { return w->err.c_str(); }
@@ -626,7 +635,8 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
     const int A = (u.enableAO == 1) ? std::max(u.aoSamples, 0) : 0;
     const int S1 = A + 6 * SPP, S2 = 6 * SPP;
 
-    if (!w->counts) { W_TRY(hipMalloc(&w->counts, (64 + 4096) * sizeof(uint32_t))); W_TRY(hipMalloc(&w->heads, 4096 * sizeof(uint32_t))); }
+    if (!w->counts) { W_TRY(hipMalloc(&w->counts, (64 + 4096) * sizeof(uint32_t))); W_TRY(hipMalloc(&w->heads, 4096 * sizeof(uint32_t)));
+        W_TRY(hipMalloc(&w->acc, 8 * sizeof(unsigned long long))); W_TRY(hipMemsetAsync(w->acc, 0, 8 * sizeof(unsigned long long), st)); }
     // per-frame arena: cand, primT, primTri, hits
     if (w->slotsCap < nSlots) {
         if (w->frameArena) (void)hipFree(w->frameArena);
@@ -727,6 +737,16 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
         hipLaunchKernelGGL(k_combine, dim3(gridH), dim3(256), 0, st, dFrame, tg, wb, c0);
         rt_stage_end(ctx, ST_COMBINE, 1);
     }
+    hipLaunchKernelGGL(k_accum_tally, dim3(1), dim3(64), 0, st, w->counts, w->acc);
     W_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+int rt_wave_traced(RtWave *w, hipStream_t st, unsigned long long *out8, bool reset) {
+    for (int i = 0; i < 8; ++i) out8[i] = 0;
+    if (!w->acc) return RT_OK;
+    W_TRY(hipStreamSynchronize(st));
+    W_TRY(hipMemcpy(out8, w->acc, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (reset) W_TRY(hipMemset(w->acc, 0, 8 * sizeof(unsigned long long)));
     return RT_OK;
 }

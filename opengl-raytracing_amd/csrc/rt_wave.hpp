@@ -14,6 +14,10 @@ const char *rt_wave_error(const RtWave *w);
 int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t stream, const rtd::DevFrame *dFrame, const rtd::DevFrame &host,
                    rtd::Targets tg, unsigned long long *counters, bool count, int treeDepth);
 
+// traced-ray tallies accumulated since the last reset: [0] candidate pixels [1] hit pixels [2] primary [3] shadow+AO
+// [4] bounce [5] bounce-shadow rays actually traversed, [6] frames
+int rt_wave_traced(RtWave *w, hipStream_t stream, unsigned long long *out8, bool reset);
+
 // stage timing hooks (rt_api.hip); stage ids index rt_stage_name()
 void rt_stage_begin(RtContext *c, int stage);
 void rt_stage_end(RtContext *c, int stage, int launches);
