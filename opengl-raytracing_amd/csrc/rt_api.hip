@@ -385,7 +385,9 @@ int rt_upload_bvh(RtContext *c, const float *nodes12, int nNodes, const float *t
     HIP_TRY(c, hipMalloc(&c->dW4, w4.size() * sizeof(float)));
     HIP_TRY(c, hipMemcpy(c->dW4, w4.data(), w4.size() * sizeof(float), hipMemcpyHostToDevice));
     c->rootRef4 = rootRef4;
-    HIP_TRY(c, hipMalloc(&c->dTris, (size_t)nTris * 12 * sizeof(float)));
+    // 8 triangles of zero padding: the traversal kernels load triangle records in groups without a bounds branch
+    HIP_TRY(c, hipMalloc(&c->dTris, (size_t)(nTris + 8) * 12 * sizeof(float)));
+    HIP_TRY(c, hipMemset(c->dTris, 0, (size_t)(nTris + 8) * 12 * sizeof(float)));
     HIP_TRY(c, hipMemcpy(c->dWNodes, wn.data(), wn.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->dTris, tris12, (size_t)nTris * 12 * sizeof(float), hipMemcpyHostToDevice));
     c->nNodes = nNodes; c->nTris = nTris; c->nInner = nInner; c->treeDepth = depth;

@@ -259,3 +259,77 @@ def test_render_ray_mirrors_mainloop(ren, orc):
     assert ren.frame_index == 3
     ren.reset_accum()
     assert ren.frame_index == 0
+
+
+def test_wavefront_chunked_queues_match_unchunked(orc):
+    """Ray queues are processed in chunks of hits when the frame does not fit the queue budget; the chunked run
+    (RT_QUEUE_BUDGET_MB=1 -> 4096-hit chunks) must be bit-identical to the oracle as well."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import opengl_raytracing_amd as rt, oracle as orc, scenes
+W, H = 200, 120
+nodes, tris = scenes.bunny_bvh(4); faces = scenes.tiny_env(16)
+p = rt.default_render_params(); p.sppPerFrame = 2
+cam = scenes.camera("closeup", aspect=W / H)
+with rt.Renderer(pipeline=rt.RT_PIPELINE_WAVEFRONT) as r:
+    r.upload_bvh(nodes, tris); r.upload_env(faces); r.resize(W, H)
+    prev = None
+    for f in range(2):
+        u = rt.frame_uniforms(p, cam, W, H, f, True, nodes.shape[0], tris.shape[0])
+        r.render_frame(u)
+        want, _ = orc.render(u, nodes, tris, faces, prev)
+        for g, w in zip(r.read_all(), want):
+            assert np.array_equal(g, w)
+        prev = want[0]
+print("CHUNKED-OK")
+'''
+    env = dict(os.environ, RT_QUEUE_BUDGET_MB="1")
+    out = subprocess.run([sys.executable, "-c", code], cwd=str(scenes.ROOT), env=env, capture_output=True, text=True, timeout=300)
+    assert "CHUNKED-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("pipeline", ["mega", "wave"])
+@pytest.mark.parametrize("use_bvh", [False, True])
+def test_moving_camera_reprojection(orc, pipeline, use_bvh):
+    """Camera path: rt_render_ray keeps FrameState (prev/curr view-projection), raises cameraMoved, switches the
+    jitter scale (application.cpp:387-405); the shader writes motion vectors and resolveTAA takes the reprojection
+    branch (rt_taa.glsl:116-179), with the (4,4) disocclusion marker on misses (rt.frag:172-175)."""
+    if pipeline == "wave" and not use_bvh:
+        pytest.skip("the analytic scene always runs in the megakernel")
+    W, H = 160, 96
+    nodes, tris = scenes.bunny_bvh(3)
+    faces = scenes.tiny_env(8)
+    p = rt.default_render_params()
+    p.sppPerFrame = 2
+    cam = scenes.camera("closeup" if use_bvh else "default", aspect=W / H)
+    pipe = rt.RT_PIPELINE_MEGAKERNEL if pipeline == "mega" else rt.RT_PIPELINE_WAVEFRONT
+    with rt.Renderer(pipeline=pipe) as r:
+        r.upload_bvh(nodes, tris)
+        r.upload_env(faces)
+        r.resize(W, H)
+        prev, prev_vp = None, None
+        moved_frames = 0
+        for frame in range(5):
+            if frame in (1, 2, 4):          # move on some frames, hold still on others
+                cam.pos[0] += 0.03
+                cam.yaw += 0.4
+            view, proj = orc.camera_view(cam), orc.camera_proj(cam)
+            vp = orc.mat4_mul(proj, view)
+            if prev_vp is None:
+                prev_vp = vp
+            moved = orc.camera_moved(vp, prev_vp)
+            moved_frames += int(moved)
+            u = orc.make_uniforms(orc.default_render_params() if False else p, cam, view, vp, prev_vp, W, H, frame, moved, use_bvh, False,
+                                  nodes.shape[0], tris.shape[0], True)
+            r.render_ray(p, cam, use_bvh=use_bvh)
+            want, _ = orc.render(u, nodes, tris, faces, prev)
+            _assert_targets_equal(r.read_all(), want, orc, f"moving {pipeline} bvh={use_bvh} frame={frame}")
+            if moved:
+                mot = orc.half_to_float(want[1])
+                assert np.abs(mot).max() > 0       # real motion vectors were produced
+            prev, prev_vp = want[0], vp
+        assert moved_frames == 3
