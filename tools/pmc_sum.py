@@ -1,5 +1,7 @@
 import csv, glob, sys, collections, re
 out = sys.argv[1]
+frames = int(sys.argv[sys.argv.index('--frames') + 1]) if '--frames' in sys.argv else 1
+import json
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 def short(name):
     m = re.search(r'(k_\w+)(<[^>]*>)?', name)
@@ -16,3 +18,12 @@ for k, d in sorted(agg.items()):
     if g("SQ_WAVE_CYCLES") and g("SQ_WAIT_ANY"): print(f"  wait_frac={g('SQ_WAIT_ANY')/g('SQ_WAVE_CYCLES'):.2f} issue_frac={g('SQ_ACTIVE_INST_ANY',0)/g('SQ_WAVE_CYCLES'):.2f}", end='')
     if g("TCP_TOTAL_CACHE_ACCESSES_sum"): print(f"  L1hit={1-g('TCP_TCC_READ_REQ_sum',0)/g('TCP_TOTAL_CACHE_ACCESSES_sum'):.2f} L2hit={g('TCC_HIT_sum',0)/max(g('TCC_HIT_sum',0)+g('TCC_MISS_sum',0),1):.2f}", end='')
     print()
+
+# HBM traffic per frame, per kernel (FETCH_SIZE / WRITE_SIZE are in KB; gfx950 FETCH_SIZE under-reports wide reads by 2x:
+# MI355X_MICROARCH.md "HBM" -- both raw and corrected figures are kept)
+tr = {}
+for k, d in agg.items():
+    if "FETCH_SIZE" in d or "WRITE_SIZE" in d:
+        tr[k] = {"fetch_kb_raw_per_frame": d.get("FETCH_SIZE", 0) / frames, "write_kb_per_frame": d.get("WRITE_SIZE", 0) / frames,
+                 "hbm_bytes_per_frame_corrected": (2 * d.get("FETCH_SIZE", 0) + d.get("WRITE_SIZE", 0)) * 1024 / frames}
+json.dump({"frames_profiled": frames, "kernels": tr}, open(out + "/traffic.json", "w"), indent=1)
