@@ -55,6 +55,7 @@ struct WaveBuf {
     HitRec *hits;
     // per chunk of CH hits
     float4 *shO, *shD;       // shadow queue 1: (A + 6*SPP) slots x CH
+    float *shT, *giL, *sh2T; // per-slot tMax (any-hit) / liveness (bounce); < 0 = no ray in this slot (4 B instead of a 32-B record)
     uint8_t *occ1;
     float4 *giO, *giD;       // bounce queue: SPP slots x CH
     float *giT;
@@ -177,6 +178,7 @@ struct PrimarySrc {   // ray i = primary ray of candidate i
 };
 struct QueueSrc {     // slot-major queue: ray r -> (slot = r / n, j = r % n) at [slot*stride + j], n = live entries
     const float4 *o, *d;
+    const float *tm;             // per-slot tMax / liveness
     const uint32_t *liveCount;   // device counter the live entry count derives from
     uint32_t c0, cap, stride, slots;
     float *outT;
@@ -189,24 +191,32 @@ struct QueueSrc {     // slot-major queue: ray r -> (slot = r / n, j = r % n) at
     RT_DEV bool load(uint32_t r, V3 &ro, V3 &rd, float &tMax, uint32_t &token) const {
         uint32_t a = addr(r);
         token = a;                       // results go to the same queue address: no second div/mod at retirement
+        tMax = tm[a];                    // 4-byte, coalesced liveness probe: dead slots never touch the 32-byte record
+        if (tMax < 0.0f) return false;
         float4 oo = o[a];
-        float4 dd = d[a];                // both halves in flight together; dead slots (w < 0) are rare
-        ro = f4xyz(oo); rd = f4xyz(dd); tMax = oo.w;
-        return oo.w >= 0.0f;
+        float4 dd = d[a];
+        ro = f4xyz(oo); rd = f4xyz(dd);
+        return true;
     }
     RT_DEV void store_closest(uint32_t a, float t, int tri) const { outT[a] = t; outTri[a] = tri; }
     RT_DEV void store_any(uint32_t a, bool occ) const { outOcc[a] = occ ? 1 : 0; }
 };
 
 // Tunables of the scheduler (overridable per context through RT_REFILL_MIN / RT_MIN_SEARCH for experiments).
+constexpr uint32_t kShards = 64, kShardStride = 32;   // cursor shards per trace launch, uint32 words between them (128 B)
+constexpr uint32_t kHeadWords = kShards * kShardStride;
+
 struct TraceTune { int refillMin; int minSearch; int chunk; int leafb; };
 
 template <bool ANY> struct StackOf { typedef StackEntry type; };          // closest: {deferred child, its entry distance}
 template <> struct StackOf<true> { typedef uint32_t type; };              // any-hit: the pop-time cull never fires (tMax is constant)
 
-template <class Src, bool ANY, int STACK, int LEAFB>
+template <class Src, bool ANY, int STACK, int LEAFB, bool STATS = false>
 __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, const float4 *__restrict__ wnodes, const float4 *__restrict__ tris, Src src,
-                                                uint32_t *head, uint32_t *tally, TraceTune tune) {
+                                                uint32_t *head, uint32_t *tally, TraceTune tune, unsigned long long *stats = nullptr) {
+    // STATS (diagnostic build only, RT_TRACE_STATS=1): [0] inner-node visits [1] leaf visits [2] triangle tests [3] inner-phase wave
+    // iterations [4] active lanes summed over them [5] leaf-phase wave iterations [6] lanes with a leaf summed [7] refill rounds
+    unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     typedef typename StackOf<ANY>::type Entry;
     __shared__ Entry lds[4 * STACK * 64];
     Entry *stk = &lds[(threadIdx.x >> 6) * STACK * 64 + (threadIdx.x & 63)];
@@ -217,8 +227,7 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
     src.prepare();
     const uint32_t n = src.size();
     const uint32_t lane = threadIdx.x & 63;
-    // run length per reservation: ~8 runs per wave, so the tail stays balanced and the cursor stays cold
-    const uint32_t chunk = max(64u, min((uint32_t)tune.chunk, n / (gridDim.x * 4u * 8u)));
+    const uint32_t runLen = (uint32_t)max(tune.chunk, 64);
 
     // per-lane ray state
     V3 ro = mk3(0.0f), rd = mk3(0.0f), rdInv = mk3(0.0f);
@@ -229,7 +238,8 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
     bool active = false;
     bool exhausted = (n == 0);
     uint32_t traced = 0;
-    uint32_t runNext = 0, runEnd = 0;   // wave-uniform: this wave's reserved run of ray indices
+    uint32_t runNext = 0, runEnd = 0;   // wave-uniform: the part of the current run not handed out yet
+    uint32_t shard = (blockIdx.x * 4u + (threadIdx.x >> 6)) % kShards, dryShards = 0;
 
     // pop the next subtree of this lane's ray, or retire the ray
     auto pop_or_finish = [&]() {
@@ -256,19 +266,27 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
     };
 
     for (;;) {
-        // ---- scheduler: idle lanes take the next rays of this wave's reserved run; a new run of
-        // `tune.chunk` consecutive rays costs ONE atomic on the global cursor (a single cursor word
-        // saturates near 88 M atomics/s on MI355X, so per-refill atomics would bound the kernel).
+        // ---- scheduler: idle lanes take the next rays of this wave's current run (`runLen` consecutive rays: same ray
+        // type, neighbouring pixels).  Runs are dealt by kShards cursors, each on its own 128-byte line: shard s owns
+        // runs s, s+kShards, ...; a wave draws from its home shard and steals round-robin once that is dry.  (One shared
+        // cursor word sustains only ~88 M atomics/s on MI355X -- per-refill, then per-run atomics on a single word
+        // bounded earlier versions of this kernel; a purely static deal leaves the bounce-ray tail unbalanced.)
         unsigned long long idleMask = __ballot(!active);
         int nIdle = __popcll(idleMask);
         if (!exhausted && nIdle >= tune.refillMin) {
+            if (STATS && lane == 0) st_[7]++;
             if (runNext >= runEnd) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(head, chunk);
-                base = __shfl(base, 0, 64);
-                runNext = base;
-                runEnd = min(base + chunk, n);
-                if (base >= n) { exhausted = true; continue; }
+                uint32_t k = 0;
+                if (lane == 0) k = atomicAdd(&head[shard * kShardStride], 1u);
+                k = __shfl(k, 0, 64);
+                const unsigned long long base = ((unsigned long long)k * kShards + shard) * runLen;
+                if (base >= n) {                      // this shard is dry: move on, give up after a full round
+                    shard = (shard + 1u) % kShards;
+                    if (++dryShards >= kShards) exhausted = true;
+                    continue;
+                }
+                runNext = (uint32_t)base;
+                runEnd = (uint32_t)min((unsigned long long)n, base + runLen);
             }
             const uint32_t take = min((uint32_t)nIdle, runEnd - runNext);
             if (!active) {
@@ -307,7 +325,9 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
             const unsigned long long sm = __ballot(searching);
             if (sm == 0ull) break;
             if (__popcll(sm) < tune.minSearch && __ballot(active && ref < 0) != 0ull) break;   // keep the leaf phase dense
+            if (STATS && lane == 0) { st_[3]++; st_[4] += (unsigned long long)__popcll(sm); }
             if (searching) {
+                if (STATS) st_[0]++;
                 if constexpr (ANY) {
                     // 4-wide node: up to four grandchild boxes per 128-byte record, order irrelevant for any-hit
                     const float4 *nd = nodes + (size_t)ref * 8;
@@ -347,7 +367,9 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
             }
         }
         // ---- phase 2: leaves
+        if (STATS) { unsigned long long lm = __ballot(active && ref < 0); if (lane == 0 && lm) { st_[5]++; st_[6] += (unsigned long long)__popcll(lm); } }
         if (active && ref < 0) {
+            if (STATS) st_[1]++;
             int v = -ref - 1;
             int first = v >> 3, count = (v & 7) + 1;
             bool done = false;
@@ -361,6 +383,7 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
 #pragma unroll
                 for (int k = 0; k < LEAFB; ++k) {
                     float tt;
+                    if (STATS && !done && i + k < count) st_[2]++;
                     if (!done && i + k < count && tri_hit(ro, rd, f4xyz(rec[k][0]), f4xyz(rec[k][1]), f4xyz(rec[k][2]), eps, tBest, tt)) {
                         if (ANY) done = true;
                         else { tBest = tt; triBest = first + i + k; }
@@ -371,6 +394,13 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
                 src.store_any(rayId, true);
                 active = false;
             } else pop_or_finish();
+        }
+    }
+    if (STATS && stats) {
+        for (int q = 0; q < 8; ++q) {
+            unsigned long long v = st_[q];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if (lane == 0 && v) atomicAdd(&stats[q], v);
         }
     }
     if (tally) {
@@ -416,21 +446,24 @@ struct GenDirectTracer {   // records first-generation rays of (hit j, sample s)
     RT_DEV bool shadow(int, int k, V3 ro, V3 rd, float tMax, bool matters) {
         uint32_t a = (uint32_t)(wb.A + s * 6 + k) * wb.CH + j;
         shadowMask |= 1u << k;
-        if (!matters) { wb.shO[a] = make_float4(0, 0, 0, -1.0f); return false; }   // dead ray: its answer is multiplied by zero
-        wb.shO[a] = mkf4(ro, fmaxr(tMax, 0.0f));
+        if (!matters) { wb.shT[a] = -1.0f; return false; }   // dead ray: its answer is multiplied by zero
+        wb.shT[a] = fmaxr(tMax, 0.0f);
+        wb.shO[a] = mkf4(ro, 0.0f);
         wb.shD[a] = mkf4(rd, 0.0f);
         return false;
     }
     RT_DEV int gi(V3 ro, V3 rd, V3 &, V3 &) {
         uint32_t a = (uint32_t)s * wb.CH + j;
-        wb.giO[a] = mkf4(ro, 1.0f);
+        wb.giL[a] = 1.0f;
+        wb.giO[a] = mkf4(ro, 0.0f);
         wb.giD[a] = mkf4(rd, 0.0f);
         giCast = true;
         return -1;
     }
     RT_DEV bool ao(int i, V3 org, V3 dir, float radius) {
         uint32_t a = (uint32_t)i * wb.CH + j;
-        wb.shO[a] = mkf4(org, below(radius));   // closest t < radius  <=>  any hit with t <= pred(radius)
+        wb.shT[a] = below(radius);   // closest t < radius  <=>  any hit with t <= pred(radius)
+        wb.shO[a] = mkf4(org, 0.0f);
         wb.shD[a] = mkf4(dir, 0.0f);
         return false;
     }
@@ -447,8 +480,9 @@ struct GenGiTracer {       // reads the bounce result, records the shadow rays a
         if (seg != SEG_GI_DIRECT) return false;
         uint32_t a = (uint32_t)k * (wb.CH * (uint32_t)wb.SPP) + pos;
         shadowMask |= 1u << k;
-        if (!matters) { wb.sh2O[a] = make_float4(0, 0, 0, -1.0f); return false; }
-        wb.sh2O[a] = mkf4(ro, fmaxr(tMax, 0.0f));
+        if (!matters) { wb.sh2T[a] = -1.0f; return false; }
+        wb.sh2T[a] = fmaxr(tMax, 0.0f);
+        wb.sh2O[a] = mkf4(ro, 0.0f);
         wb.sh2D[a] = mkf4(rd, 0.0f);
         return false;
     }
@@ -513,10 +547,10 @@ __global__ __launch_bounds__(256) void k_gen_direct(const DevFrame *__restrict__
     tr.wb = wb; tr.j = j; tr.s = s; tr.shadowMask = 0; tr.giCast = false;
     (void)directLightBVH(tr, c.F, SEG_DIRECT, c.hp, c.hn, seed, -c.dir);
     for (int k = 4; k < 6; ++k)   // sun / point rays are conditional (rt_lighting.glsl:123,194)
-        if (!(tr.shadowMask & (1u << k))) wb.shO[(uint32_t)(wb.A + s * 6 + k) * wb.CH + j] = make_float4(0, 0, 0, -1.0f);
+        if (!(tr.shadowMask & (1u << k))) wb.shT[(uint32_t)(wb.A + s * 6 + k) * wb.CH + j] = -1.0f;
     Work w;
     if (u.enableGI == 1) (void)oneBounceGIBVH<GenDirectTracer, false>(tr, c.F, c.hp, c.hn, u.frameIndex, seed, w);
-    if (!tr.giCast) wb.giO[(uint32_t)s * wb.CH + j] = make_float4(0, 0, 0, -1.0f);
+    if (!tr.giCast) wb.giL[(uint32_t)s * wb.CH + j] = -1.0f;
     if (s == 0 && wb.A > 0) (void)computeAO_BVH(tr, c.F, c.hp, c.hn, u.frameIndex);
 }
 
@@ -529,7 +563,7 @@ __global__ __launch_bounds__(256) void k_gen_gi(const DevFrame *__restrict__ fr,
     const int s = mine ? (int)(tid / live) : 0;
     const uint32_t j = mine ? tid % live : 0;
     const uint32_t a = (uint32_t)s * wb.CH + j;
-    const bool bounced = mine && wb.giO[a].w >= 0.0f && wb.giTri[a] >= 0;
+    const bool bounced = mine && wb.giL[a] >= 0.0f && wb.giTri[a] >= 0;
     const uint32_t pos = block_append(bounced, giCount);   // compact the (hit, sample) pairs that need second-generation rays
     if (!mine) return;
     wb.giPos[a] = bounced ? (int)pos : -1;
@@ -542,7 +576,7 @@ __global__ __launch_bounds__(256) void k_gen_gi(const DevFrame *__restrict__ fr,
     Work w;
     (void)oneBounceGIBVH<GenGiTracer, false>(tr, c.F, c.hp, c.hn, u.frameIndex, seed, w);
     for (int k = 0; k < 6; ++k)
-        if (!(tr.shadowMask & (1u << k))) wb.sh2O[(uint32_t)k * (wb.CH * (uint32_t)wb.SPP) + pos] = make_float4(0, 0, 0, -1.0f);
+        if (!(tr.shadowMask & (1u << k))) wb.sh2T[(uint32_t)k * (wb.CH * (uint32_t)wb.SPP) + pos] = -1.0f;
 }
 
 // ---- stage: combine (thread = hit) ---------------------------------------------------------------
@@ -578,7 +612,8 @@ __global__ void k_accum_tally(const uint32_t *counts, unsigned long long *acc) {
 }
 
 template <class Src, bool ANY>
-void launch_trace(hipStream_t st, int cus, int depth, const DevFrame *fr, const DevScene &hs, Src src, uint32_t *head, uint32_t *tally, TraceTune tune) {
+void launch_trace(hipStream_t st, int cus, int depth, const DevFrame *fr, const DevScene &hs, Src src, uint32_t *head, uint32_t *tally, TraceTune tune,
+                  unsigned long long *stats = nullptr) {
     // Stack entries: closest-hit defers one sibling per binary level (8 B each); any-hit walks 4-wide nodes and can
     // defer three per two levels (4 B each).  Resident 256-thread blocks per CU follow from the LDS footprint.
     const int need = ANY ? 3 * ((depth + 1) / 2) : depth;
@@ -587,7 +622,8 @@ void launch_trace(hipStream_t st, int cus, int depth, const DevFrame *fr, const 
     const int perCU = std::max(1, std::min(8, (160 * 1024) / (256 * stack * (ANY ? 4 : 8))));
     const float4 *nodes = ANY ? hs.w4 : hs.wnodes;
     dim3 g((unsigned)(cus * perCU)), b(256);
-#define RT_LAUNCH_TRACE(ST, LB) hipLaunchKernelGGL((k_trace<Src, ANY, ST, LB>), g, b, 0, st, fr, nodes, hs.tris, src, head, tally, tune)
+#define RT_LAUNCH_TRACE(ST, LB) do { if (stats) hipLaunchKernelGGL((k_trace<Src, ANY, ST, LB, true>), g, b, 0, st, fr, nodes, hs.tris, src, head, tally, tune, stats); \
+        else hipLaunchKernelGGL((k_trace<Src, ANY, ST, LB, false>), g, b, 0, st, fr, nodes, hs.tris, src, head, tally, tune, (unsigned long long *)nullptr); } while (0)
 #define RT_LAUNCH_TRACE_LB(ST) do { if (tune.leafb >= 4) RT_LAUNCH_TRACE(ST, 4); else if (tune.leafb >= 2) RT_LAUNCH_TRACE(ST, 2); else RT_LAUNCH_TRACE(ST, 1); } while (0)
     if (stack == s0) RT_LAUNCH_TRACE_LB((ANY ? 24 : 16));
     else if (stack == s1) RT_LAUNCH_TRACE_LB((ANY ? 36 : 24));
@@ -599,17 +635,20 @@ void launch_trace(hipStream_t st, int cus, int depth, const DevFrame *fr, const 
 }  // namespace
 
 // -------------------------------------------------------------------------------------------------
+constexpr int kMaxLaunches = 256;   // trace launches per frame (1 + 3 per chunk) the cursor table is sized for
+
 struct RtWave {
     std::string err;
     int cus = 256;
     size_t budgetBytes = (size_t)8 << 30;   // ray-queue budget per context; 288 GB of HBM make this cheap
-    TraceTune tune{32, 16, 2048, 2};
+    TraceTune tune{32, 16, 64, 2};
     // allocations
     size_t slotsCap = 0;      // per-frame arrays sized for this many pixel slots
     size_t chunkBytes = 0;    // bytes of the per-chunk arena
     void *frameArena = nullptr, *chunkArena = nullptr;
     uint32_t *counts = nullptr, *heads = nullptr;
     unsigned long long *acc = nullptr;   // traced-ray tallies accumulated over frames
+    unsigned long long *stats = nullptr; // RT_TRACE_STATS=1: 4 stages x 8 diagnostic sums
 };
 
 RtWave *rt_wave_create(int cus) {
@@ -650,7 +689,7 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
     const int A = (u.enableAO == 1) ? std::max(u.aoSamples, 0) : 0;
     const int S1 = A + 6 * SPP, S2 = 6 * SPP;
 
-    if (!w->counts) { W_TRY(hipMalloc(&w->counts, (64 + 4096) * sizeof(uint32_t))); W_TRY(hipMalloc(&w->heads, 4096 * sizeof(uint32_t)));
+    if (!w->counts) { W_TRY(hipMalloc(&w->counts, (64 + 4096) * sizeof(uint32_t))); W_TRY(hipMalloc(&w->heads, (size_t)kMaxLaunches * kHeadWords * sizeof(uint32_t)));
         W_TRY(hipMalloc(&w->acc, 8 * sizeof(unsigned long long))); W_TRY(hipMemsetAsync(w->acc, 0, 8 * sizeof(unsigned long long), st)); }
     // per-frame arena: cand, primT, primTri, hits
     if (w->slotsCap < nSlots) {
@@ -660,11 +699,12 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
         w->slotsCap = nSlots;
     }
     // chunk capacity from the budget
-    const size_t perHit = (size_t)(S1 + SPP + S2) * 32 + (size_t)S1 + (size_t)SPP * 12 + (size_t)S2;
+    const size_t perHit = (size_t)(S1 + SPP + S2) * 36 + (size_t)S1 + (size_t)SPP * 12 + (size_t)S2;
     size_t CH = std::min(nSlots, std::max<size_t>(w->budgetBytes / perHit, 4096));
     CH = align_up(CH, 256);
     const size_t need = align_up(CH * (size_t)S1 * 32, 256) + align_up(CH * (size_t)S1, 256) + align_up(CH * (size_t)SPP * 32, 256) +
-                        align_up(CH * (size_t)SPP * 8, 256) + align_up(CH * (size_t)S2 * 32, 256) + align_up(CH * (size_t)S2, 256) + align_up(CH * (size_t)SPP * 4, 256) + 4096;
+                        align_up(CH * (size_t)SPP * 8, 256) + align_up(CH * (size_t)S2 * 32, 256) + align_up(CH * (size_t)S2, 256) + align_up(CH * (size_t)SPP * 4, 256) +
+                        align_up(CH * (size_t)S1 * 4, 256) + align_up(CH * (size_t)SPP * 4, 256) + align_up(CH * (size_t)S2 * 4, 256) + 4096;
     if (w->chunkBytes < need) {
         if (w->chunkArena) (void)hipFree(w->chunkArena);
         w->chunkArena = nullptr;
@@ -688,15 +728,18 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
         wb.sh2O = (float4 *)take(CH * (size_t)S2 * 16); wb.sh2D = (float4 *)take(CH * (size_t)S2 * 16);
         wb.occ2 = (uint8_t *)take(CH * (size_t)S2);
         wb.giPos = (int *)take(CH * (size_t)SPP * 4);
+        wb.shT = (float *)take(CH * (size_t)S1 * 4); wb.giL = (float *)take(CH * (size_t)SPP * 4); wb.sh2T = (float *)take(CH * (size_t)S2 * 4);
     }
     wb.counts = w->counts; wb.heads = w->heads;
     wb.CH = (uint32_t)CH; wb.A = A; wb.SPP = SPP;
     const int nChunks = (int)((nSlots + CH - 1) / CH);
-    if (nChunks > 1000) { w->err = "too many chunks for the cursor table; raise RT_QUEUE_BUDGET_MB"; return RT_ERR_UNSUPPORTED; }
+    if (1 + nChunks * 3 > kMaxLaunches) { w->err = "too many chunks for the cursor table; raise RT_QUEUE_BUDGET_MB"; return RT_ERR_UNSUPPORTED; }
 
     W_TRY(hipMemsetAsync(w->counts, 0, (size_t)(64 + nChunks) * sizeof(uint32_t), st));
-    W_TRY(hipMemsetAsync(w->heads, 0, (size_t)(1 + nChunks * 3) * sizeof(uint32_t), st));
+    W_TRY(hipMemsetAsync(w->heads, 0, (size_t)(1 + nChunks * 3) * kHeadWords * sizeof(uint32_t), st));
     const int traceBlocks = w->cus;
+    if (getenv("RT_TRACE_STATS") && !w->stats) { W_TRY(hipMalloc(&w->stats, 32 * sizeof(unsigned long long))); W_TRY(hipMemset(w->stats, 0, 32 * sizeof(unsigned long long))); }
+    unsigned long long *S = w->stats;
     const TraceTune tune = w->tune;
     const unsigned tiles = (unsigned)std::max(host.g.nLocalTiles, 0);
     if (tiles == 0) return RT_OK;
@@ -708,7 +751,7 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
     rt_stage_begin(ctx, ST_TRACE_PRIMARY);
     PrimarySrc ps;
     ps.fr = dFrame; ps.cand = wb.cand; ps.count = &wb.counts[0]; ps.outT = wb.primT; ps.outTri = wb.primTri;
-    launch_trace<PrimarySrc, false>(st, traceBlocks, treeDepth, dFrame, host.sc, ps, &wb.heads[0], &wb.counts[2], tune);
+    launch_trace<PrimarySrc, false>(st, traceBlocks, treeDepth, dFrame, host.sc, ps, &wb.heads[0], &wb.counts[2], tune, S ? S + 0 : nullptr);
     rt_stage_end(ctx, ST_TRACE_PRIMARY, 1);
 
     rt_stage_begin(ctx, ST_POST_PRIMARY);
@@ -723,18 +766,18 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
         rt_stage_end(ctx, ST_GEN_DIRECT, 1);
 
         QueueSrc q1;
-        q1.o = wb.shO; q1.d = wb.shD; q1.liveCount = &wb.counts[1]; q1.c0 = c0; q1.cap = wb.CH; q1.stride = wb.CH; q1.slots = (uint32_t)S1;
+        q1.o = wb.shO; q1.d = wb.shD; q1.tm = wb.shT; q1.liveCount = &wb.counts[1]; q1.c0 = c0; q1.cap = wb.CH; q1.stride = wb.CH; q1.slots = (uint32_t)S1;
         q1.outT = nullptr; q1.outTri = nullptr; q1.outOcc = wb.occ1;
         rt_stage_begin(ctx, ST_TRACE_SHADOW);
-        launch_trace<QueueSrc, true>(st, traceBlocks, treeDepth, dFrame, host.sc, q1, &wb.heads[1 + c * 3 + 0], &wb.counts[3], tune);
+        launch_trace<QueueSrc, true>(st, traceBlocks, treeDepth, dFrame, host.sc, q1, &wb.heads[(size_t)(1 + c * 3 + 0) * kHeadWords], &wb.counts[3], tune, S ? S + 8 : nullptr);
         rt_stage_end(ctx, ST_TRACE_SHADOW, 1);
 
         if (u.enableGI == 1) {
             QueueSrc qg;
-            qg.o = wb.giO; qg.d = wb.giD; qg.liveCount = &wb.counts[1]; qg.c0 = c0; qg.cap = wb.CH; qg.stride = wb.CH; qg.slots = (uint32_t)SPP;
+            qg.o = wb.giO; qg.d = wb.giD; qg.tm = wb.giL; qg.liveCount = &wb.counts[1]; qg.c0 = c0; qg.cap = wb.CH; qg.stride = wb.CH; qg.slots = (uint32_t)SPP;
             qg.outT = wb.giT; qg.outTri = wb.giTri; qg.outOcc = nullptr;
             rt_stage_begin(ctx, ST_TRACE_GI);
-            launch_trace<QueueSrc, false>(st, traceBlocks, treeDepth, dFrame, host.sc, qg, &wb.heads[1 + c * 3 + 1], &wb.counts[4], tune);
+            launch_trace<QueueSrc, false>(st, traceBlocks, treeDepth, dFrame, host.sc, qg, &wb.heads[(size_t)(1 + c * 3 + 1) * kHeadWords], &wb.counts[4], tune, S ? S + 16 : nullptr);
             rt_stage_end(ctx, ST_TRACE_GI, 1);
 
             rt_stage_begin(ctx, ST_GEN_GI);
@@ -742,10 +785,10 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
             rt_stage_end(ctx, ST_GEN_GI, 1);
 
             QueueSrc q2;
-            q2.o = wb.sh2O; q2.d = wb.sh2D; q2.liveCount = &wb.counts[64 + c]; q2.c0 = 0; q2.cap = wb.CH * (uint32_t)SPP; q2.stride = wb.CH * (uint32_t)SPP; q2.slots = 6u;
+            q2.o = wb.sh2O; q2.d = wb.sh2D; q2.tm = wb.sh2T; q2.liveCount = &wb.counts[64 + c]; q2.c0 = 0; q2.cap = wb.CH * (uint32_t)SPP; q2.stride = wb.CH * (uint32_t)SPP; q2.slots = 6u;
             q2.outT = nullptr; q2.outTri = nullptr; q2.outOcc = wb.occ2;
             rt_stage_begin(ctx, ST_TRACE_GI_SHADOW);
-            launch_trace<QueueSrc, true>(st, traceBlocks, treeDepth, dFrame, host.sc, q2, &wb.heads[1 + c * 3 + 2], &wb.counts[5], tune);
+            launch_trace<QueueSrc, true>(st, traceBlocks, treeDepth, dFrame, host.sc, q2, &wb.heads[(size_t)(1 + c * 3 + 2) * kHeadWords], &wb.counts[5], tune, S ? S + 24 : nullptr);
             rt_stage_end(ctx, ST_TRACE_GI_SHADOW, 1);
         }
         rt_stage_begin(ctx, ST_COMBINE);
@@ -762,6 +805,18 @@ int rt_wave_traced(RtWave *w, hipStream_t st, unsigned long long *out8, bool res
     if (!w->acc) return RT_OK;
     W_TRY(hipStreamSynchronize(st));
     W_TRY(hipMemcpy(out8, w->acc, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (w->stats) {
+        unsigned long long v[32];
+        W_TRY(hipMemcpy(v, w->stats, sizeof v, hipMemcpyDeviceToHost));
+        static const char *nm[4] = {"primary", "shadow", "bounce", "bounce_shadow"};
+        for (int k = 0; k < 4; ++k) {
+            const unsigned long long *q = v + k * 8;
+            double rays = (double)std::max<unsigned long long>(out8[2 + k], 1);
+            fprintf(stderr, "[trace stats] %-13s rays %.3g | per ray: inner %.1f leaf %.1f tri %.1f | inner-phase lane util %.2f (%.3g wave-iters) leaf-phase util %.2f (%.3g) | refill rounds %.3g\n",
+                    nm[k], rays, q[0] / rays, q[1] / rays, q[2] / rays, q[3] ? q[4] / (64.0 * q[3]) : 0.0, (double)q[3], q[5] ? q[6] / (64.0 * q[5]) : 0.0, (double)q[5], (double)q[7]);
+        }
+        if (reset) W_TRY(hipMemset(w->stats, 0, sizeof v));
+    }
     if (reset) W_TRY(hipMemset(w->acc, 0, 8 * sizeof(unsigned long long)));
     return RT_OK;
 }
