@@ -201,19 +201,19 @@ void *target_ptr(RtContext *c, int which, int &channels) {
 
 // ------------------------------------------------------------------------------------------------
 // stage timing helpers (used by rt_wave.hip through RtStageTimer)
-void rt_stage_begin(RtContext *c, int stage) {
+void rt_stage_begin(RtContext *c, int stage, hipStream_t on) {
     if (!c->timing) return;
     StageEvent ev;
     ev.stage = stage;
     if (!c->freeEvents.empty()) { ev.a = c->freeEvents.back().first; ev.b = c->freeEvents.back().second; c->freeEvents.pop_back(); }
     else { (void)hipEventCreate(&ev.a); (void)hipEventCreate(&ev.b); }
-    (void)hipEventRecord(ev.a, c->stream);
+    (void)hipEventRecord(ev.a, on ? on : c->stream);
     c->pending.push_back(ev);
 }
-void rt_stage_end(RtContext *c, int stage, int launches) {
+void rt_stage_end(RtContext *c, int stage, int launches, hipStream_t on) {
     if (!c->timing) return;
     for (size_t i = c->pending.size(); i-- > 0;)
-        if (c->pending[i].stage == stage) { (void)hipEventRecord(c->pending[i].b, c->stream); break; }
+        if (c->pending[i].stage == stage) { (void)hipEventRecord(c->pending[i].b, on ? on : c->stream); break; }
     c->stageLaunches[stage] += (uint64_t)launches;
 }
 static void resolve_stage_events(RtContext *c) {
@@ -375,6 +375,12 @@ int rt_upload_bvh(RtContext *c, const float *nodes12, int nNodes, const float *t
                     float *o = &w4[jb.at * 32 + (size_t)i * 8];
                     o[0] = b[0]; o[1] = b[1]; o[2] = b[2];
                     o[4] = b[4]; o[5] = b[5]; o[6] = b[6];
+                } else {
+                    // absent child: NaN box -- (NaN - ro) * rdInv = NaN, v_min/v_max drop NaN operands, tmax = NaN, and
+                    // "tmax >= tmin" is false, so the traversal kernel needs no child-present branch
+                    float *o = &w4[jb.at * 32 + (size_t)i * 8];
+                    const float qnan = std::nanf("");
+                    o[0] = o[1] = o[2] = o[4] = o[5] = o[6] = qnan;
                 }
                 std::memcpy(&w4[jb.at * 32 + (size_t)i * 8 + 3], &ref, 4);
             }

@@ -202,6 +202,11 @@ struct QueueSrc {     // slot-major queue: ray r -> (slot = r / n, j = r % n) at
     RT_DEV void store_any(uint32_t a, bool occ) const { outOcc[a] = occ ? 1 : 0; }
 };
 
+// hipcc sinks loads into the branches that first use them (e.g. a triangle's v0 behind the determinant test), which turns
+// one gather round trip into two or three dependent ones.  pin() makes a loaded record "used" right after the loads were
+// issued, so the whole group is in flight together.
+RT_DEV void pin(float4 &v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+
 // Tunables of the scheduler (overridable per context through RT_REFILL_MIN / RT_MIN_SEARCH for experiments).
 constexpr uint32_t kShards = 64, kShardStride = 32;   // cursor shards per trace launch, uint32 words between them (128 B)
 constexpr uint32_t kHeadWords = kShards * kShardStride;
@@ -332,12 +337,15 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
                     // 4-wide node: up to four grandchild boxes per 128-byte record, order irrelevant for any-hit
                     const float4 *nd = nodes + (size_t)ref * 8;
                     float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3], q4 = nd[4], q5 = nd[5], q6 = nd[6], q7 = nd[7];
+                    pin(q0); pin(q1); pin(q2); pin(q3); pin(q4); pin(q5); pin(q6); pin(q7);
                     int r0 = (int)f2u(q0.w), r1 = (int)f2u(q2.w), r2 = (int)f2u(q4.w), r3 = (int)f2u(q6.w);
                     float t0, t1, t2, t3;
                     bool h0 = slab(ro, rdInv, f4xyz(q0), f4xyz(q1), t0) && t0 <= tBest;
                     bool h1 = slab(ro, rdInv, f4xyz(q2), f4xyz(q3), t1) && t1 <= tBest;
-                    bool h2 = r2 != RT_NO_CHILD && slab(ro, rdInv, f4xyz(q4), f4xyz(q5), t2) && t2 <= tBest;
-                    bool h3 = r3 != RT_NO_CHILD && slab(ro, rdInv, f4xyz(q6), f4xyz(q7), t3) && t3 <= tBest;
+                    // absent children carry NaN boxes: with v_min/v_max NaN semantics their slab test is false, so all eight
+                    // loads are issued up front and the four tests are branch-free (no dependent "is there a child" round trip)
+                    bool h2 = slab(ro, rdInv, f4xyz(q4), f4xyz(q5), t2) && t2 <= tBest;
+                    bool h3 = slab(ro, rdInv, f4xyz(q6), f4xyz(q7), t3) && t3 <= tBest;
                     int nxt = RT_NO_CHILD;
                     if (h0) nxt = r0;
                     if (h1) { if (nxt == RT_NO_CHILD) nxt = r1; else { stk[sp * 64] = (uint32_t)r1; sp++; } }
@@ -348,6 +356,7 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
                 } else {
                     const float4 *nd = nodes + (size_t)ref * 4;
                     float4 a = nd[0], b = nd[1], c = nd[2], d = nd[3];
+                    pin(a); pin(b); pin(c); pin(d);
                     float tL, tR;
                     bool hitL = slab(ro, rdInv, f4xyz(a), f4xyz(b), tL) && tL <= tBest;
                     bool hitR = slab(ro, rdInv, f4xyz(c), f4xyz(d), tR) && tR <= tBest;
@@ -380,6 +389,8 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
                 float4 rec[LEAFB][3];
 #pragma unroll
                 for (int k = 0; k < LEAFB; ++k) { rec[k][0] = t[k * 3 + 0]; rec[k][1] = t[k * 3 + 1]; rec[k][2] = t[k * 3 + 2]; }
+#pragma unroll
+                for (int k = 0; k < LEAFB; ++k) { pin(rec[k][0]); pin(rec[k][1]); pin(rec[k][2]); }
 #pragma unroll
                 for (int k = 0; k < LEAFB; ++k) {
                     float tt;
@@ -649,6 +660,9 @@ struct RtWave {
     uint32_t *counts = nullptr, *heads = nullptr;
     unsigned long long *acc = nullptr;   // traced-ray tallies accumulated over frames
     unsigned long long *stats = nullptr; // RT_TRACE_STATS=1: 4 stages x 8 diagnostic sums
+    hipStream_t side = nullptr;          // second stream for the bounce branch
+    hipEvent_t evFork = nullptr, evJoin = nullptr;
+    bool overlap = false;   // RT_OVERLAP=1: measured no wall-time gain on MI355X (the traversal grids already saturate the CUs)
 };
 
 RtWave *rt_wave_create(int cus) {
@@ -657,6 +671,7 @@ RtWave *rt_wave_create(int cus) {
     if (const char *e = getenv("RT_QUEUE_BUDGET_MB")) w->budgetBytes = (size_t)atoll(e) << 20;
     if (const char *e = getenv("RT_REFILL_MIN")) w->tune.refillMin = std::max(1, std::min(64, atoi(e)));
     if (const char *e = getenv("RT_CHUNK")) w->tune.chunk = std::max(64, std::min(1 << 20, atoi(e)));
+    if (const char *e = getenv("RT_OVERLAP")) w->overlap = atoi(e) != 0;
     if (const char *e = getenv("RT_LEAFB")) w->tune.leafb = atoi(e);
     if (const char *e = getenv("RT_MIN_SEARCH")) w->tune.minSearch = std::max(0, std::min(64, atoi(e)));
     return w;
@@ -668,6 +683,10 @@ void rt_wave_destroy(RtWave *w) {
     if (w->counts) (void)hipFree(w->counts);
     if (w->heads) (void)hipFree(w->heads);
     if (w->acc) (void)hipFree(w->acc);
+    if (w->stats) (void)hipFree(w->stats);
+    if (w->side) (void)hipStreamDestroy(w->side);
+    if (w->evFork) (void)hipEventDestroy(w->evFork);
+    if (w->evJoin) (void)hipEventDestroy(w->evJoin);
     delete w;
 }
 const char *rt_wave_error(const RtWave *w) { return w->err.c_str(); }
@@ -689,6 +708,13 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
     const int A = (u.enableAO == 1) ? std::max(u.aoSamples, 0) : 0;
     const int S1 = A + 6 * SPP, S2 = 6 * SPP;
 
+    if (!w->side) {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // hi = numerically lowest = highest priority
+        W_TRY(hipStreamCreateWithPriority(&w->side, hipStreamNonBlocking, hi));
+        W_TRY(hipEventCreateWithFlags(&w->evFork, hipEventDisableTiming));
+        W_TRY(hipEventCreateWithFlags(&w->evJoin, hipEventDisableTiming));
+    }
     if (!w->counts) { W_TRY(hipMalloc(&w->counts, (64 + 4096) * sizeof(uint32_t))); W_TRY(hipMalloc(&w->heads, (size_t)kMaxLaunches * kHeadWords * sizeof(uint32_t)));
         W_TRY(hipMalloc(&w->acc, 8 * sizeof(unsigned long long))); W_TRY(hipMemsetAsync(w->acc, 0, 8 * sizeof(unsigned long long), st)); }
     // per-frame arena: cand, primT, primTri, hits
@@ -765,32 +791,38 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
         hipLaunchKernelGGL(k_gen_direct, dim3(gridHS), dim3(256), 0, st, dFrame, wb, c0);
         rt_stage_end(ctx, ST_GEN_DIRECT, 1);
 
+        // The bounce branch (trace_gi -> gen_gi -> trace_gi_shadow) and the direct shadow traversal only share their
+        // producer (gen_direct) and consumer (combine): the bounce branch runs on a second, higher-priority stream so that
+        // its kernels fill the ramp-down tails of the persistent traversal grids instead of waiting behind them.
+        hipStream_t sg = (w->overlap && u.enableGI == 1) ? w->side : st;
+        if (sg != st) { W_TRY(hipEventRecord(w->evFork, st)); W_TRY(hipStreamWaitEvent(sg, w->evFork, 0)); }
+        if (u.enableGI == 1) {
+            QueueSrc qg;
+            qg.o = wb.giO; qg.d = wb.giD; qg.tm = wb.giL; qg.liveCount = &wb.counts[1]; qg.c0 = c0; qg.cap = wb.CH; qg.stride = wb.CH; qg.slots = (uint32_t)SPP;
+            qg.outT = wb.giT; qg.outTri = wb.giTri; qg.outOcc = nullptr;
+            rt_stage_begin(ctx, ST_TRACE_GI, sg);
+            launch_trace<QueueSrc, false>(sg, traceBlocks, treeDepth, dFrame, host.sc, qg, &wb.heads[(size_t)(1 + c * 3 + 1) * kHeadWords], &wb.counts[4], tune, S ? S + 16 : nullptr);
+            rt_stage_end(ctx, ST_TRACE_GI, 1, sg);
+        }
         QueueSrc q1;
         q1.o = wb.shO; q1.d = wb.shD; q1.tm = wb.shT; q1.liveCount = &wb.counts[1]; q1.c0 = c0; q1.cap = wb.CH; q1.stride = wb.CH; q1.slots = (uint32_t)S1;
         q1.outT = nullptr; q1.outTri = nullptr; q1.outOcc = wb.occ1;
         rt_stage_begin(ctx, ST_TRACE_SHADOW);
         launch_trace<QueueSrc, true>(st, traceBlocks, treeDepth, dFrame, host.sc, q1, &wb.heads[(size_t)(1 + c * 3 + 0) * kHeadWords], &wb.counts[3], tune, S ? S + 8 : nullptr);
         rt_stage_end(ctx, ST_TRACE_SHADOW, 1);
-
         if (u.enableGI == 1) {
-            QueueSrc qg;
-            qg.o = wb.giO; qg.d = wb.giD; qg.tm = wb.giL; qg.liveCount = &wb.counts[1]; qg.c0 = c0; qg.cap = wb.CH; qg.stride = wb.CH; qg.slots = (uint32_t)SPP;
-            qg.outT = wb.giT; qg.outTri = wb.giTri; qg.outOcc = nullptr;
-            rt_stage_begin(ctx, ST_TRACE_GI);
-            launch_trace<QueueSrc, false>(st, traceBlocks, treeDepth, dFrame, host.sc, qg, &wb.heads[(size_t)(1 + c * 3 + 1) * kHeadWords], &wb.counts[4], tune, S ? S + 16 : nullptr);
-            rt_stage_end(ctx, ST_TRACE_GI, 1);
-
-            rt_stage_begin(ctx, ST_GEN_GI);
-            hipLaunchKernelGGL(k_gen_gi, dim3(gridHS), dim3(256), 0, st, dFrame, wb, c0, &wb.counts[64 + c]);
-            rt_stage_end(ctx, ST_GEN_GI, 1);
+            rt_stage_begin(ctx, ST_GEN_GI, sg);
+            hipLaunchKernelGGL(k_gen_gi, dim3(gridHS), dim3(256), 0, sg, dFrame, wb, c0, &wb.counts[64 + c]);
+            rt_stage_end(ctx, ST_GEN_GI, 1, sg);
 
             QueueSrc q2;
             q2.o = wb.sh2O; q2.d = wb.sh2D; q2.tm = wb.sh2T; q2.liveCount = &wb.counts[64 + c]; q2.c0 = 0; q2.cap = wb.CH * (uint32_t)SPP; q2.stride = wb.CH * (uint32_t)SPP; q2.slots = 6u;
             q2.outT = nullptr; q2.outTri = nullptr; q2.outOcc = wb.occ2;
-            rt_stage_begin(ctx, ST_TRACE_GI_SHADOW);
-            launch_trace<QueueSrc, true>(st, traceBlocks, treeDepth, dFrame, host.sc, q2, &wb.heads[(size_t)(1 + c * 3 + 2) * kHeadWords], &wb.counts[5], tune, S ? S + 24 : nullptr);
-            rt_stage_end(ctx, ST_TRACE_GI_SHADOW, 1);
+            rt_stage_begin(ctx, ST_TRACE_GI_SHADOW, sg);
+            launch_trace<QueueSrc, true>(sg, traceBlocks, treeDepth, dFrame, host.sc, q2, &wb.heads[(size_t)(1 + c * 3 + 2) * kHeadWords], &wb.counts[5], tune, S ? S + 24 : nullptr);
+            rt_stage_end(ctx, ST_TRACE_GI_SHADOW, 1, sg);
         }
+        if (sg != st) { W_TRY(hipEventRecord(w->evJoin, sg)); W_TRY(hipStreamWaitEvent(st, w->evJoin, 0)); }
         rt_stage_begin(ctx, ST_COMBINE);
         hipLaunchKernelGGL(k_combine, dim3(gridH), dim3(256), 0, st, dFrame, tg, wb, c0);
         rt_stage_end(ctx, ST_COMBINE, 1);

@@ -19,5 +19,5 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t stream, const rtd::Dev
 int rt_wave_traced(RtWave *w, hipStream_t stream, unsigned long long *out8, bool reset);
 
 // stage timing hooks (rt_api.hip); stage ids index rt_stage_name()
-void rt_stage_begin(RtContext *c, int stage);
-void rt_stage_end(RtContext *c, int stage, int launches);
+void rt_stage_begin(RtContext *c, int stage, hipStream_t on = nullptr);   // on == nullptr: the context's stream
+void rt_stage_end(RtContext *c, int stage, int launches, hipStream_t on = nullptr);
