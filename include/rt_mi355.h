@@ -171,6 +171,17 @@ int rt_synchronize(RtContext *ctx);
  * widening).  With worldSize > 1 only this rank's tiles are filled, the rest is zero. */
 int rt_read_target(RtContext *ctx, int which, void *dst, int dstFormat);
 
+/* Present pass of renderRay (src/render/render.cpp:199-239 = shaders/rt/rt_present.frag): SVGF-lite 7x7 filter,
+ * ACES, gamma 1/2.2 (or the motion visualisation) over the four targets of the last frame -> RGBA8, width*height*4
+ * bytes, row 0 = bottom.  RtPresentParams = the uniforms of rt_present.frag:38-50; rt_make_present_params fills
+ * them from RenderParams as render.cpp:209-235 does.  Single-rank contexts only (the 7x7 taps cross tile borders). */
+typedef struct RtPresentParams {
+    float exposure; int32_t showMotion; float motionScale; float resolution[2];
+    float varMax, kVar, kColor, kVarMotion, kColorMotion, svgfStrength; int32_t enableSVGF;
+} RtPresentParams;
+void rt_make_present_params(const RtRenderParams *p, int showMotion, int fbw, int fbh, RtPresentParams *out);
+int rt_present(RtContext *ctx, const RtPresentParams *p, uint8_t *dstRGBA8);
+
 /* Tile-parallel plumbing for the RCCL gather (one process per GPU; the collective itself is
  * issued by the host through torch.distributed / RCCL on these device pointers).
  * Local layout: [localTile][RT_TILE_PIXELS][channels] halfs, localTile = globalTile / worldSize for

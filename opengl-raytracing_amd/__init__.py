@@ -129,6 +129,11 @@ class RtTracedRays(_Struct):
         return self.primary + self.shadow + self.bounce + self.bounceShadow
 
 
+class RtPresentParams(_Struct):  # uniforms of shaders/rt/rt_present.frag:38-50
+    _fields_ = _fields([("exposure", f32), ("showMotion", i32), ("motionScale", f32), ("resolution", (f32, 2)), ("varMax", f32), ("kVar", f32),
+                        ("kColor", f32), ("kVarMotion", f32), ("kColorMotion", f32), ("svgfStrength", f32), ("enableSVGF", i32)])
+
+
 class RtError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"rt_mi355 error {code}: {msg}")
@@ -154,6 +159,8 @@ SIGNATURES = {
     "rt_render_ray": (C.c_int, [C.c_void_p, C.POINTER(RtRenderParams), C.POINTER(RtCamera), C.c_int, C.c_int, _FP, _FP]),
     "rt_synchronize": (C.c_int, [C.c_void_p]),
     "rt_read_target": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
+    "rt_make_present_params": (None, [C.POINTER(RtRenderParams), C.c_int, C.c_int, C.c_int, C.POINTER(RtPresentParams)]),
+    "rt_present": (C.c_int, [C.c_void_p, C.POINTER(RtPresentParams), _U8P]),
     "rt_local_target": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "rt_gather_block_bytes": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]),
     "rt_assemble_gathered": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
@@ -279,6 +286,12 @@ def make_uniforms(params, cam, view, curr_vp, prev_vp, w, h, frame_index=0, came
                            int(camera_moved), int(use_bvh), int(show_motion), int(node_count), int(tri_count), int(env_loaded),
                            C.byref(u))
     return u
+
+
+def make_present_params(params, show_motion, w, h) -> RtPresentParams:
+    pp = RtPresentParams()
+    lib().rt_make_present_params(C.byref(params), int(show_motion), int(w), int(h), C.byref(pp))
+    return pp
 
 
 def gather_triangles(positions, indices, model=None) -> np.ndarray:
@@ -416,6 +429,13 @@ class Renderer:
         ch = TARGET_CHANNELS[which]
         out = np.zeros((self.height, self.width, ch), np.uint16 if fmt == RT_FORMAT_F16 else np.float32)
         self._check(lib().rt_read_target(self._h, which, out.ctypes.data_as(C.c_void_p), fmt))
+        return out
+
+    def present(self, params, show_motion=False) -> np.ndarray:
+        """Present pass over the last frame -> [H, W, 4] uint8 (row 0 = bottom)."""
+        pp = make_present_params(params, show_motion, self.width, self.height)
+        out = np.zeros((self.height, self.width, 4), np.uint8)
+        self._check(lib().rt_present(self._h, C.byref(pp), out.ctypes.data_as(_U8P)))
         return out
 
     def read_all(self):

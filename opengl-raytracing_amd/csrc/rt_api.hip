@@ -71,7 +71,7 @@ static int fail(RtContext *c, int code, const char *fmt, ...) {
     } while (0)
 
 static const char *kStageNames[RT_MAX_STAGES] = {"mega",     "primary", "trace_primary",   "post_primary", "gen_direct", "trace_shadow",
-                                                 "trace_gi", "gen_gi",  "trace_gi_shadow", "combine",      "assemble",   ""};
+                                                 "trace_gi", "gen_gi",  "trace_gi_shadow", "combine",      "assemble",   "present"};
 
 // ------------------------------------------------------------------------------------------------
 namespace {
@@ -552,6 +552,23 @@ int rt_read_target(RtContext *c, int which, void *dst, int fmt) {
     return RT_OK;
 }
 
+int rt_present(RtContext *c, const RtPresentParams *p, uint8_t *dst) {
+    if (!c || !p || !dst) return RT_ERR_INVALID;
+    if (!c->sized) return fail(c, RT_ERR_STATE, "rt_present before rt_resize");
+    if (c->g.world > 1) return fail(c, RT_ERR_UNSUPPORTED, "rt_present: the 7x7 filter reads other ranks' tiles; present on the gathering rank needs all four targets gathered (not in this build)");
+    if ((int)p->resolution[0] != c->g.W || (int)p->resolution[1] != c->g.H) return fail(c, RT_ERR_INVALID, "rt_present: uResolution != framebuffer");
+    (void)hipSetDevice(c->cfg.device);
+    const size_t bytes = (size_t)c->g.W * c->g.H * 4;
+    int rc = ensure_staging(c, bytes);
+    if (rc != RT_OK) return rc;
+    rt_stage_begin(c, 11);
+    HIP_TRY(c, rtl::launch_present(c->stream, c->g, c->dColor[1 - c->writeIdx], c->dMotion, c->dGPos, c->dGNrm, *p, (uint32_t *)c->dStaging));
+    rt_stage_end(c, 11, 1);
+    HIP_TRY(c, hipMemcpyAsync(dst, c->dStaging, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
 int rt_local_target(RtContext *c, int which, void **devPtr, size_t *bytes) {
     if (!c || !devPtr || !bytes) return RT_ERR_INVALID;
     if (!c->sized) return fail(c, RT_ERR_STATE, "rt_local_target before rt_resize");
@@ -629,7 +646,7 @@ int rt_get_stage_times(RtContext *c, RtStageTimes *out) {
     if (!c || !out) return RT_ERR_INVALID;
     (void)hipSetDevice(c->cfg.device);
     resolve_stage_events(c);
-    out->nStages = 11;
+    out->nStages = 12;
     out->frames = c->timedFrames;
     for (int i = 0; i < RT_MAX_STAGES; ++i) { out->ms[i] = c->stageMs[i]; out->launches[i] = c->stageLaunches[i]; }
     return RT_OK;

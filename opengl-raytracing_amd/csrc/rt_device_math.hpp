@@ -124,6 +124,28 @@ RT_DEV float powr(float x, float y) {
     return exp2r(y * log2r(x));
 }
 
+RT_DEV float expr(float x) { return exp2r(x * 0x1.715476p+0f); }
+RT_DEV float atanpolyr(float z) {
+    float w = z * z;
+    float p = __builtin_fmaf(w, 0.0028662257f, -0.0161657367f);
+    p = __builtin_fmaf(p, w, 0.0429096138f);
+    p = __builtin_fmaf(p, w, -0.0752896400f);
+    p = __builtin_fmaf(p, w, 0.1065626393f);
+    p = __builtin_fmaf(p, w, -0.1420889944f);
+    p = __builtin_fmaf(p, w, 0.1999355085f);
+    p = __builtin_fmaf(p, w, -0.3333314528f);
+    p = __builtin_fmaf(p, w, 1.0f);
+    return z * p;
+}
+RT_DEV float atan2r(float y, float x) {
+    const float PI = 3.14159265358979f, PIO2 = 1.57079632679490f;
+    float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
+    if (ax == 0.0f && ay == 0.0f) return 0.0f;
+    float a = (ay > ax) ? PIO2 - atanpolyr(ax / ay) : atanpolyr(ay / ax);
+    if (x < 0.0f) a = PI - a;
+    return (y < 0.0f) ? -a : a;
+}
+
 // binary32 -> binary16 bit pattern, round-to-nearest-even (v_cvt_f16_f32).
 RT_DEV uint16_t f32_to_f16_bits(float f) {
     _Float16 h = (_Float16)f;

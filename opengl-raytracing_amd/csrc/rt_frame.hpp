@@ -94,6 +94,8 @@ RT_DEV void flush_work(const Work &w, unsigned long long *counters) {
 // ---- launchers implemented in the kernel translation units --------------------------------------
 struct RtWaveBuffers;   // rt_wave.hip
 namespace rtl {
+hipError_t launch_present(hipStream_t s, const rtd::FrameGeom &g, const uint2 *color, const uint32_t *motion, const uint2 *gpos,
+                          const uint2 *gnrm, const RtPresentParams &p, uint32_t *outRGBA8);
 hipError_t launch_mega(hipStream_t s, const rtd::DevFrame *frame, rtd::Targets tg, unsigned long long *counters, bool count,
                        int stackDepth, int nLocalTiles);
 }

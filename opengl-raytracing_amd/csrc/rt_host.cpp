@@ -350,6 +350,13 @@ void rt_make_uniforms(const RtRenderParams *p, const RtCamera *cam, const float 
     u->matMirrorGloss = p->matMirrorGloss; u->matMirrorEnabled = p->matMirrorEnabled;
 }
 
+void rt_make_present_params(const RtRenderParams *p, int showMotion, int fbw, int fbh, RtPresentParams *o) {   // render.cpp:209-235
+    o->exposure = p->exposure; o->showMotion = showMotion ? 1 : 0; o->motionScale = p->motionScale;
+    o->resolution[0] = (float)fbw; o->resolution[1] = (float)fbh;
+    o->varMax = p->svgfVarMax; o->kVar = p->svgfKVar; o->kColor = p->svgfKColor; o->kVarMotion = p->svgfKVarMotion;
+    o->kColorMotion = p->svgfKColorMotion; o->svgfStrength = p->svgfStrength; o->enableSVGF = p->enableSVGF ? 1 : 0;
+}
+
 int rt_gather_triangles(const float *positions, const uint32_t *indices, int nIdx, const float *M, float *out) {
     if (!positions || !indices || !M || !out || nIdx < 0) return RT_ERR_INVALID;
     auto world = [&](uint32_t vi) {

@@ -137,6 +137,29 @@ static inline float powf_(float x, float y) {
     return exp2f_(y * log2f_(x));
 }
 
+// exp(x) = exp2(x * log2(e)); atan2 through the 8-term A&S 4.4.49 odd polynomial on [-1, 1] (present pass only)
+static inline float expf_(float x) { return exp2f_(x * 0x1.715476p+0f); }
+static inline float atanpoly_(float z) {   // |z| <= 1
+    float w = z * z;
+    float p = std::fmaf(w, 0.0028662257f, -0.0161657367f);
+    p = std::fmaf(p, w, 0.0429096138f);
+    p = std::fmaf(p, w, -0.0752896400f);
+    p = std::fmaf(p, w, 0.1065626393f);
+    p = std::fmaf(p, w, -0.1420889944f);
+    p = std::fmaf(p, w, 0.1999355085f);
+    p = std::fmaf(p, w, -0.3333314528f);
+    p = std::fmaf(p, w, 1.0f);
+    return z * p;
+}
+static inline float atan2f_(float y, float x) {
+    const float PI = 3.14159265358979f, PIO2 = 1.57079632679490f;
+    float ax = std::fabs(x), ay = std::fabs(y);
+    if (ax == 0.0f && ay == 0.0f) return 0.0f;
+    float a = (ay > ax) ? PIO2 - atanpoly_(ax / ay) : atanpoly_(ay / ax);
+    if (x < 0.0f) a = PI - a;
+    return (y < 0.0f) ? -a : a;
+}
+
 // ---- fp16 (IEEE binary16) round-to-nearest-even, the conversion GL applies on RGBA16F stores --
 static inline uint16_t f32_to_f16(float f) {
     uint32_t x = f2u(f);

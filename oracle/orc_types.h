@@ -64,6 +64,12 @@ typedef struct OrcRenderParams {
 // include/io/Camera.h:21-109 (state only).
 typedef struct OrcCamera { float pos[3], yaw, pitch, fov, aspect; } OrcCamera;
 
+// Uniforms of shaders/rt/rt_present.frag:38-50 as set at src/render/render.cpp:209-235.
+typedef struct OrcPresentParams {
+    float exposure; int32_t showMotion; float motionScale; float resolution[2];
+    float varMax, kVar, kColor, kVarMotion, kColorMotion, svgfStrength; int32_t enableSVGF;
+} OrcPresentParams;
+
 typedef struct OrcCounters {
     uint64_t raysClosest;     // traceBVH calls
     uint64_t raysShadow;      // traceBVHShadow calls

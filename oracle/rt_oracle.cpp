@@ -834,3 +834,147 @@ int orc_render(const OrcUniforms *u, const float *nodes12, const float *tris12, 
 }
 
 }  // extern "C"
+
+// ================================================================================================
+// Present pass: shaders/rt/rt_present.frag (SVGF-lite 7x7 + ACES + gamma), uniforms as set at
+// src/render/render.cpp:206-235.  Inputs are the four targets of the frame just rendered (NEAREST,
+// CLAMP_TO_EDGE: src/render/accum.cpp:11-14, gbuffer.cpp:16-19); output = default framebuffer RGBA8.
+namespace orc {
+
+struct PresentIn {
+    const uint16_t *color, *motion, *gpos, *gnrm;
+    int W, H;
+    OrcPresentParams p;
+};
+static vec4 tex4(const uint16_t *img, int W, int H, float u, float v) {   // texture(sampler2D, uv), NEAREST
+    int x = (int)std::floor(u * (float)W), y = (int)std::floor(v * (float)H);
+    x = std::min(std::max(x, 0), W - 1);
+    y = std::min(std::max(y, 0), H - 1);
+    const uint16_t *p = img + ((size_t)y * W + x) * 4;
+    return {f16_to_f32(p[0]), f16_to_f32(p[1]), f16_to_f32(p[2]), f16_to_f32(p[3])};
+}
+static vec2 tex2(const uint16_t *img, int W, int H, float u, float v) {
+    int x = (int)std::floor(u * (float)W), y = (int)std::floor(v * (float)H);
+    x = std::min(std::max(x, 0), W - 1);
+    y = std::min(std::max(y, 0), H - 1);
+    const uint16_t *p = img + ((size_t)y * W + x) * 2;
+    return {f16_to_f32(p[0]), f16_to_f32(p[1])};
+}
+static vec3 acesTonemap(vec3 x, float exposure) {                        // rt_present.frag:65-69
+    x = x * exposure;
+    const float a = 2.51f, b = 0.03f, c = 2.43f, d = 0.59f, e = 0.14f;
+    vec3 num = x * (a * x + v3(b));
+    vec3 den = x * (c * x + v3(d)) + v3(e);
+    return {clampf(num.x / den.x, 0.0f, 1.0f), clampf(num.y / den.y, 0.0f, 1.0f), clampf(num.z / den.z, 0.0f, 1.0f)};
+}
+static vec3 hsv2rgb(vec3 c) {                                            // :74-77
+    vec3 q = {fractf(c.x + 0.0f), fractf(c.x + 2.0f / 3.0f), fractf(c.x + 1.0f / 3.0f)};
+    vec3 p = {std::fabs(q.x * 6.0f - 3.0f), std::fabs(q.y * 6.0f - 3.0f), std::fabs(q.z * 6.0f - 3.0f)};
+    vec3 k = {clampf(p.x - 1.0f, 0.0f, 1.0f), clampf(p.y - 1.0f, 0.0f, 1.0f), clampf(p.z - 1.0f, 0.0f, 1.0f)};
+    return c.z * mix(v3(1.0f), k, c.y);
+}
+static vec3 visualizeMotion(vec2 motion, float scale) {                  // :92-104
+    vec2 m = {motion.x * scale, motion.y * scale};
+    float mag = length(m);
+    if (mag < 1e-4f) return v3(0.0f);
+    float hue = atan2f_(m.y, m.x) / (2.0f * 3.1415926535f) + 0.5f;
+    float val = clampf(mag, 0.0f, 1.0f);
+    return hsv2rgb(v3(hue, 1.0f, val));
+}
+static vec3 svgfFilter(const PresentIn &I, float u, float v) {           // :126-225
+    const OrcPresentParams &P = I.p;
+    const vec3 Y = {0.299f, 0.587f, 0.114f};
+    vec4 centerRaw = tex4(I.color, I.W, I.H, u, v);
+    vec3 cCenter = {centerRaw.x, centerRaw.y, centerRaw.z};
+    float lCenter = dot(cCenter, Y);
+    float varCenter = fmax_(centerRaw.w - lCenter * lCenter, 0.0f);
+    varCenter = fmin_(varCenter, P.varMax);
+    vec2 motion = tex2(I.motion, I.W, I.H, u, v);
+    float motMag = length(motion);
+    vec4 pc = tex4(I.gpos, I.W, I.H, u, v), nc = tex4(I.gnrm, I.W, I.H, u, v);
+    vec3 pCenter = {pc.x, pc.y, pc.z}, nCenter = {nc.x, nc.y, nc.z};
+    float texelX = 1.0f / P.resolution[0], texelY = 1.0f / P.resolution[1];
+    vec3 accumCol = v3(0.0f);
+    float accumW = 0.0f;
+    float t = clampf(smoothstepf(0.005f, 0.05f, motMag), 0.0f, 1.0f);
+    float kVar = mixf(P.kVar, P.kVarMotion, t);
+    float kColor = mixf(P.kColor, P.kColorMotion, t);
+    const float K_NRM = 2.0f, K_POS = 0.02f;
+    float varBoost = 1.0f + varCenter * (1.0f + kVar * 0.5f);
+    for (int j = -3; j <= 3; ++j)
+        for (int i = -3; i <= 3; ++i) {
+            float un = u + (float)i * texelX, vn = v + (float)j * texelY;
+            if (un < 0.0f || un > 1.0f || vn < 0.0f || vn > 1.0f) continue;
+            vec4 s = tex4(I.color, I.W, I.H, un, vn);
+            vec3 c = {s.x, s.y, s.z};
+            vec3 dc = c - cCenter;
+            float dc2 = dot(dc, dc);
+            float wCol = expf_(-dc2 * (kColor * 0.3f + 0.05f));
+            vec4 p4 = tex4(I.gpos, I.W, I.H, un, vn), n4 = tex4(I.gnrm, I.W, I.H, un, vn);
+            vec3 p = {p4.x, p4.y, p4.z}, n = {n4.x, n4.y, n4.z};
+            vec3 dp = p - pCenter;
+            float dist2 = dot(dp, dp);
+            float wPos = expf_(-dist2 * K_POS);
+            float ndot = clampf(dot(normalize(nCenter), normalize(n)), -1.0f, 1.0f);
+            float nDiff = fmax_(0.0f, 1.0f - ndot);
+            float wNrm = expf_(-nDiff * K_NRM);
+            float wSpatial = (i == 0 && j == 0) ? 1.0f : 1.0f + varCenter * 4.0f;
+            float w = varBoost * wCol * wPos * wNrm * wSpatial;
+            accumCol += c * w;
+            accumW += w;
+        }
+    if (accumW <= 0.0f) return cCenter;
+    return accumCol / accumW;
+}
+static uint8_t unorm8(float x) {   // GL float -> UNORM8 conversion: clamp, scale, round to nearest
+    float c = clampf(x, 0.0f, 1.0f);
+    if (c != c) c = 0.0f;
+    return (uint8_t)std::rint(c * 255.0f);
+}
+static void presentPixel(const PresentIn &I, int px, int py, uint8_t *out) {   // main(), :231-266
+    const OrcPresentParams &P = I.p;
+    float u = (((float)px + 0.5f) + 0.5f) / (float)I.W, v = (((float)py + 0.5f) + 0.5f) / (float)I.H;   // (gl_FragCoord.xy + 0.5) / size
+    vec3 rgb;
+    if (P.showMotion == 1) {
+        vec2 m = tex2(I.motion, I.W, I.H, u, v);
+        rgb = visualizeMotion(m, P.motionScale);
+    } else {
+        vec4 rawc = tex4(I.color, I.W, I.H, u, v);
+        vec3 raw = {rawc.x, rawc.y, rawc.z};
+        vec3 linearColor;
+        if (P.enableSVGF == 0) linearColor = raw;
+        else {
+            vec3 filtered = svgfFilter(I, u, v);
+            float s = clampf(P.svgfStrength, 0.0f, 1.0f);
+            linearColor = mix(raw, filtered, s);
+        }
+        vec3 mapped = acesTonemap(linearColor, P.exposure);
+        rgb = {powf_(mapped.x, 1.0f / 2.2f), powf_(mapped.y, 1.0f / 2.2f), powf_(mapped.z, 1.0f / 2.2f)};
+    }
+    out[0] = unorm8(rgb.x); out[1] = unorm8(rgb.y); out[2] = unorm8(rgb.z); out[3] = 255;
+}
+
+}  // namespace orc
+
+extern "C" int orc_present(const OrcPresentParams *p, const uint16_t *color, const uint16_t *motion, const uint16_t *gpos,
+                           const uint16_t *gnrm, uint8_t *outRGBA8, int nthreads) {
+    orc::PresentIn I;
+    I.color = color; I.motion = motion; I.gpos = gpos; I.gnrm = gnrm; I.p = *p;
+    I.W = (int)p->resolution[0]; I.H = (int)p->resolution[1];
+    if (I.W <= 0 || I.H <= 0) return -1;
+    std::atomic<int> next{0};
+    auto worker = [&]() {
+        for (;;) {
+            int y = next.fetch_add(1);
+            if (y >= I.H) break;
+            for (int x = 0; x < I.W; ++x) orc::presentPixel(I, x, y, outRGBA8 + ((size_t)y * I.W + x) * 4);
+        }
+    };
+    std::vector<std::thread> th;
+    for (int i = 1; i < std::max(nthreads, 1); ++i) th.emplace_back(worker);
+    worker();
+    for (auto &t : th) t.join();
+    return 0;
+}
+extern "C" float orc_exp(float x) { return orc::expf_(x); }
+extern "C" float orc_atan2(float y, float x) { return orc::atan2f_(y, x); }

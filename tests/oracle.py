@@ -74,6 +74,10 @@ def lib():
     L.orc_gather_triangles.restype = C.c_int; L.orc_gather_triangles.argtypes = [_FP, _U32P, C.c_int, _FP, _FP]
     L.orc_build_bvh.restype = C.c_int; L.orc_build_bvh.argtypes = [_FP, C.c_int, _FP, _FP]
     L.orc_cubemap_from_cross.restype = C.c_int; L.orc_cubemap_from_cross.argtypes = [_U8P, C.c_int, C.c_int, C.c_int, _U8P]
+    L.orc_present.restype = C.c_int
+    L.orc_present.argtypes = [C.POINTER(rt.RtPresentParams), _U16P, _U16P, _U16P, _U16P, _U8P, C.c_int]
+    L.orc_exp.restype = C.c_float; L.orc_exp.argtypes = [C.c_float]
+    L.orc_atan2.restype = C.c_float; L.orc_atan2.argtypes = [C.c_float, C.c_float]
     L.orc_sizeof_uniforms.restype = C.c_int
     L.orc_sizeof_render_params.restype = C.c_int
     assert L.orc_sizeof_uniforms() == C.sizeof(rt.RtUniforms)
@@ -188,6 +192,17 @@ def render(u, nodes12=None, tris12=None, env_faces=None, prev=None, region=None,
     if rc != 0:
         raise RuntimeError(f"orc_render failed: {rc}")
     return outs, cnt
+
+
+def present(pp, targets, nthreads=8):
+    """rt_present.frag by the oracle over [color, motion, gpos, gnrm] half images -> [H, W, 4] uint8."""
+    t = [np.ascontiguousarray(a, np.uint16) for a in targets]
+    H, W = t[0].shape[:2]
+    out = np.zeros((H, W, 4), np.uint8)
+    rc = lib().orc_present(C.byref(pp), *[a.ctypes.data_as(_U16P) for a in t], out.ctypes.data_as(_U8P), nthreads)
+    if rc != 0:
+        raise RuntimeError(f"orc_present failed: {rc}")
+    return out
 
 
 def trace_bvh(u, nodes12, tris12, ro, rd):

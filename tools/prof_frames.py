@@ -3,6 +3,7 @@ import sys, argparse
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+import numpy as np
 import opengl_raytracing_amd as rt, scenes
 
 ap = argparse.ArgumentParser()
@@ -12,9 +13,15 @@ ap.add_argument("--pipeline", default="wave")
 ap.add_argument("--spp", type=int, default=4)
 ap.add_argument("--subdiv", type=int, default=6)
 ap.add_argument("--size", default="1920x1080")
+ap.add_argument("--scene", default="bunny")
 a = ap.parse_args()
 W, H = map(int, a.size.split("x"))
-nodes, tris = scenes.bunny_bvh(a.subdiv)
+import time
+if a.scene == "1m":
+    t0 = time.time(); v, f = rt.meshgen.million_triangle_scene(); tris9 = rt.gather_triangles(v, f, np.eye(4, dtype=np.float32).T.reshape(-1)); nodes, tris = rt.build_bvh(tris9)
+    print('1M scene', tris.shape, nodes.shape, 'built in', round(time.time() - t0, 1), 's')
+else:
+    nodes, tris = scenes.bunny_bvh(a.subdiv)
 faces = scenes.env_faces("Sky_01")
 p = rt.default_render_params(); p.sppPerFrame = a.spp
 cam = scenes.camera(a.camera, aspect=W / H)
