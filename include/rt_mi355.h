@@ -251,6 +251,9 @@ int rt_build_bvh(const float *tris9, int nTris, float *nodes12, float *tris12);
 int rt_load_obj(const char *path, float **positions, int *nVerts, uint32_t **indices, int *nIdx);
 /* PNG decode (8-bit RGB / RGBA / grey, non-interlaced; zlib) standing in for stbi_load at cubemap.cpp:40 */
 int rt_load_png(const char *path, uint8_t **pixels, int *width, int *height, int *channels);
+/* 8-bit PNG writer (zlib), rows top-to-bottom as stored; flipY != 0 writes the last row first, i.e. turns a
+ * bottom-up GL image the right way round */
+int rt_save_png(const char *path, const uint8_t *pixels, int width, int height, int channels, int flipY);
 void rt_free(void *p);
 
 /* The 4x3 cross slicing of loadCubeMapFromCross (src/render/cubemap.cpp:47-91).  faces needs

@@ -186,6 +186,7 @@ SIGNATURES = {
     "rt_build_bvh": (C.c_int, [_FP, C.c_int, _FP, _FP]),
     "rt_load_obj": (C.c_int, [C.c_char_p, C.POINTER(_FP), C.POINTER(C.c_int), C.POINTER(_U32P), C.POINTER(C.c_int)]),
     "rt_load_png": (C.c_int, [C.c_char_p, C.POINTER(_U8P), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "rt_save_png": (C.c_int, [C.c_char_p, _U8P, C.c_int, C.c_int, C.c_int, C.c_int]),
     "rt_free": (None, [C.c_void_p]),
     "rt_cubemap_from_cross": (C.c_int, [_U8P, C.c_int, C.c_int, C.c_int, _U8P]),
     "rt_sizeof_uniforms": (C.c_int, []),
@@ -339,6 +340,15 @@ def load_png(path) -> np.ndarray:
     a = np.ctypeslib.as_array(pix, shape=(h.value * w.value * ch.value,)).copy().reshape(h.value, w.value, ch.value)
     lib().rt_free(pix)
     return a
+
+
+def save_png(path, img, flip_y=False):
+    a = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = a.shape[:2]
+    ch = 1 if a.ndim == 2 else a.shape[2]
+    rc = lib().rt_save_png(str(path).encode(), a.ctypes.data_as(_U8P), w, h, ch, int(flip_y))
+    if rc != RT_OK:
+        raise RtError(rc, f"rt_save_png({path})")
 
 
 def cubemap_from_cross(img) -> np.ndarray:

@@ -485,6 +485,46 @@ int rt_load_png(const char *path, uint8_t **pixels, int *width, int *height, int
     return RT_OK;
 }
 
+int rt_save_png(const char *path, const uint8_t *pixels, int width, int height, int channels, int flipY) {
+    if (!path || !pixels || width <= 0 || height <= 0 || channels < 1 || channels > 4) return RT_ERR_INVALID;
+    static const uint8_t ctype[5] = {0, 0, 4, 2, 6};
+    const size_t stride = (size_t)width * channels;
+    std::vector<uint8_t> raw((stride + 1) * (size_t)height);
+    for (int y = 0; y < height; ++y) {
+        const uint8_t *src = pixels + stride * (size_t)(flipY ? height - 1 - y : y);
+        raw[(stride + 1) * (size_t)y] = 0;   // filter: none
+        std::memcpy(&raw[(stride + 1) * (size_t)y + 1], src, stride);
+    }
+    uLongf zlen = compressBound((uLong)raw.size());
+    std::vector<uint8_t> z(zlen);
+    if (compress2(z.data(), &zlen, raw.data(), (uLong)raw.size(), 6) != Z_OK) return RT_ERR_IO;
+    FILE *f = std::fopen(path, "wb");
+    if (!f) return RT_ERR_IO;
+    auto put32 = [](uint8_t *p, uint32_t v) { p[0] = (uint8_t)(v >> 24); p[1] = (uint8_t)(v >> 16); p[2] = (uint8_t)(v >> 8); p[3] = (uint8_t)v; };
+    auto chunk = [&](const char *type, const uint8_t *data, size_t len) {
+        uint8_t hdr[8];
+        put32(hdr, (uint32_t)len);
+        std::memcpy(hdr + 4, type, 4);
+        std::fwrite(hdr, 1, 8, f);
+        if (len) std::fwrite(data, 1, len, f);
+        uLong crc = crc32(0L, (const Bytef *)type, 4);
+        if (len) crc = crc32(crc, data, (uInt)len);
+        uint8_t c[4];
+        put32(c, (uint32_t)crc);
+        std::fwrite(c, 1, 4, f);
+    };
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    std::fwrite(sig, 1, 8, f);
+    uint8_t ihdr[13];
+    put32(ihdr, (uint32_t)width); put32(ihdr + 4, (uint32_t)height);
+    ihdr[8] = 8; ihdr[9] = ctype[channels]; ihdr[10] = 0; ihdr[11] = 0; ihdr[12] = 0;
+    chunk("IHDR", ihdr, 13);
+    chunk("IDAT", z.data(), zlen);
+    chunk("IEND", nullptr, 0);
+    const bool ok = std::fclose(f) == 0;
+    return ok ? RT_OK : RT_ERR_IO;
+}
+
 int rt_cubemap_from_cross(const uint8_t *img, int width, int height, int channels, uint8_t *faces) {
     if (!img || !faces || channels < 1) return 0;
     if ((height % 3) != 0 || (width % 4) != 0 || (width / 4) != (height / 3)) return 0;   // cubemap.cpp:47

@@ -1,0 +1,65 @@
+"""Headless C++ host (opengl-raytracing_amd/rt_cli, built from csrc/rt_cli.cpp): the reference's start-up + frame loop
+driven purely through the C ABI.  CPU: PNG writer round trip.  GPU: the CLI's PNG equals the frames the Python harness
+renders through the same library (and hence the oracle's, by the other parity tests)."""
+import subprocess
+
+import numpy as np
+import pytest
+
+import opengl_raytracing_amd as rt
+import scenes
+
+CLI = scenes.ROOT / "opengl-raytracing_amd" / "rt_cli"
+
+
+def test_png_writer_round_trip(tmp_path):
+    rng = np.random.default_rng(0)
+    for shape in ((7, 5, 4), (6, 9, 3), (4, 4)):
+        a = rng.integers(0, 256, size=shape, dtype=np.uint8)
+        rt.save_png(tmp_path / "a.png", a)
+        assert np.array_equal(rt.load_png(tmp_path / "a.png").reshape(a.shape), a)
+        rt.save_png(tmp_path / "f.png", a, flip_y=True)
+        assert np.array_equal(rt.load_png(tmp_path / "f.png").reshape(a.shape), a[::-1])
+    from PIL import Image
+    a = rng.integers(0, 256, size=(5, 6, 3), dtype=np.uint8)
+    rt.save_png(tmp_path / "p.png", a)
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "p.png")), a)
+    with pytest.raises(rt.RtError):
+        rt.save_png(tmp_path / "nodir" / "x.png", a)
+
+
+def test_cli_is_built_and_prints_usage():
+    assert CLI.exists(), "run __graft_entry__.build()"
+    out = subprocess.run([str(CLI), "--help"], capture_output=True, text=True)
+    assert out.returncode == 0 and "usage: rt_cli" in out.stderr
+
+
+@pytest.mark.gpu
+def test_cli_renders_the_same_frames_as_the_python_harness(tmp_path):
+    W, H, frames, spp = 160, 96, 3, 2
+    v, f = rt.meshgen.bunny_standin(3)
+    obj = tmp_path / "blob.obj"
+    rt.meshgen.write_obj(obj, v, f)
+    env = scenes.ASSETS / "Sky_16.png"
+    cam = "-2,1.5,1.0,-90,0"
+    for mode in ("bvh", "analytic"):
+        args = [str(CLI), "--env", str(env), "--size", f"{W}x{H}", "--spp", str(spp), "--frames", str(frames), "--out", str(tmp_path / mode)]
+        args += ["--obj", str(obj), "--cam", cam] if mode == "bvh" else ["--analytic"]
+        out = subprocess.run(args, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stdout + out.stderr
+        got = rt.load_png(tmp_path / f"{mode}.png")
+        # the same thing through the Python harness
+        p = rt.default_render_params()
+        p.sppPerFrame = spp
+        c = scenes.camera("closeup" if mode == "bvh" else "default", aspect=W / H)
+        with rt.Renderer() as r:
+            if mode == "bvh":
+                v2, f2 = rt.load_obj(obj)
+                nodes, tris = rt.build_bvh(rt.gather_triangles(v2, f2))
+                r.upload_bvh(nodes, tris)
+            r.upload_env(scenes.env_faces("Sky_16"))
+            r.resize(W, H)
+            for _ in range(frames):
+                r.render_ray(p, c, use_bvh=(mode == "bvh"))
+            want = r.present(p)[::-1]          # PNG rows are top-down
+        assert np.array_equal(got, want), mode
