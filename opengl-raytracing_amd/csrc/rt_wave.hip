@@ -211,7 +211,7 @@ RT_DEV void pin(float4 &v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), 
 constexpr uint32_t kShards = 64, kShardStride = 32;   // cursor shards per trace launch, uint32 words between them (128 B)
 constexpr uint32_t kHeadWords = kShards * kShardStride;
 
-struct TraceTune { int refillMin; int minSearch; int chunk; int leafb; };
+struct TraceTune { int refillMin; int minSearch; int chunk; int leafb; int skipTraversal; };   // skipTraversal: diagnostic (RT_DEBUG_SKIP_TRAVERSAL)
 
 template <bool ANY> struct StackOf { typedef StackEntry type; };          // closest: {deferred child, its entry distance}
 template <> struct StackOf<true> { typedef uint32_t type; };              // any-hit: the pop-time cull never fires (tMax is constant)
@@ -221,7 +221,8 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
                                                 uint32_t *head, uint32_t *tally, TraceTune tune, unsigned long long *stats = nullptr) {
     // STATS (diagnostic build only, RT_TRACE_STATS=1): [0] inner-node visits [1] leaf visits [2] triangle tests [3] inner-phase wave
     // iterations [4] active lanes summed over them [5] leaf-phase wave iterations [6] lanes with a leaf summed [7] refill rounds
-    unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // [8] cycles in inner steps [9] in leaf phases [10] in refills [11] wave lifetime
+    const unsigned long long tStart_ = STATS ? clock64() : 0ull;
     typedef typename StackOf<ANY>::type Entry;
     __shared__ Entry lds[4 * STACK * 64];
     Entry *stk = &lds[(threadIdx.x >> 6) * STACK * 64 + (threadIdx.x & 63)];
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
     src.prepare();
     const uint32_t n = src.size();
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t runLen = (uint32_t)max(tune.chunk, 64);
+    const uint32_t runLen = (uint32_t)max(tune.chunk, 8);
 
     // per-lane ray state
     V3 ro = mk3(0.0f), rd = mk3(0.0f), rdInv = mk3(0.0f);
@@ -244,7 +245,9 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
     bool exhausted = (n == 0);
     uint32_t traced = 0;
     uint32_t runNext = 0, runEnd = 0;   // wave-uniform: the part of the current run not handed out yet
-    uint32_t shard = (blockIdx.x * 4u + (threadIdx.x >> 6)) % kShards, dryShards = 0;
+    const uint32_t shard = (blockIdx.x * 4u + (threadIdx.x >> 6)) % kShards;   // home shard of this wave
+    bool homeDry = false;
+    const uint32_t nRuns = (n + runLen - 1u) / runLen;
 
     // pop the next subtree of this lane's ray, or retire the ray
     auto pop_or_finish = [&]() {
@@ -279,17 +282,32 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
         unsigned long long idleMask = __ballot(!active);
         int nIdle = __popcll(idleMask);
         if (!exhausted && nIdle >= tune.refillMin) {
+            const unsigned long long tR_ = STATS ? clock64() : 0ull;
             if (STATS && lane == 0) st_[7]++;
             if (runNext >= runEnd) {
-                uint32_t k = 0;
-                if (lane == 0) k = atomicAdd(&head[shard * kShardStride], 1u);
-                k = __shfl(k, 0, 64);
-                const unsigned long long base = ((unsigned long long)k * kShards + shard) * runLen;
-                if (base >= n) {                      // this shard is dry: move on, give up after a full round
-                    shard = (shard + 1u) % kShards;
-                    if (++dryShards >= kShards) exhausted = true;
-                    continue;
+                // shard s owns runs s, s + kShards, ...: k = 0 .. runsOf(s)-1
+                auto runsOf = [&](uint32_t sh) { return sh < nRuns ? (nRuns - sh + kShards - 1u) / kShards : 0u; };
+                uint32_t k = 0, from = shard;
+                bool got = false;
+                if (!homeDry) {                       // live phase: one atomic per run on the home shard
+                    if (lane == 0) k = atomicAdd(&head[shard * kShardStride], 1u);
+                    k = __shfl(k, 0, 64);
+                    got = k < runsOf(shard);
+                    homeDry = !got;
                 }
+                while (!got) {                        // stealing / drain: ONE 64-lane probe of all cursors, then one atomic
+                    const uint32_t cur = __hip_atomic_load(&head[lane * kShardStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    unsigned long long open = __ballot(cur < runsOf(lane));
+                    if (open == 0ull) break;
+                    // first open shard at or after the home shard (rotate so that waves spread over the open shards)
+                    const unsigned long long rot = (open >> shard) | (shard ? (open << (64u - shard)) : 0ull);
+                    from = (shard + (uint32_t)__ffsll((long long)rot) - 1u) % kShards;
+                    if (lane == 0) k = atomicAdd(&head[from * kShardStride], 1u);
+                    k = __shfl(k, 0, 64);
+                    got = k < runsOf(from);           // lost a race for the last run of that shard: probe again
+                }
+                if (!got) { exhausted = true; continue; }
+                const unsigned long long base = ((unsigned long long)k * kShards + from) * runLen;
                 runNext = (uint32_t)base;
                 runEnd = (uint32_t)min((unsigned long long)n, base + runLen);
             }
@@ -310,7 +328,7 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
                         sp = 0;
                         ref = ANY ? sc.rootRef4 : sc.rootRef;
                         float tmin;
-                        bool in = sc.hasBVH && slab(ro, rdInv, ld3(sc.rootMin), ld3(sc.rootMax), tmin) && !(tmin > tBest);
+                        bool in = sc.hasBVH && !tune.skipTraversal && slab(ro, rdInv, ld3(sc.rootMin), ld3(sc.rootMax), tmin) && !(tmin > tBest);
                         if (in) active = true;
                         else if (ANY) src.store_any(token, false);
                         else src.store_closest(token, inf, -1);
@@ -318,6 +336,7 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
                 }
             }
             runNext += take;
+            if (STATS && lane == 0) st_[10] += clock64() - tR_;
             continue;   // lanes that drew a dead slot or a root miss may draw again
         }
         if (__ballot(active) == 0ull) {
@@ -330,6 +349,7 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
             const unsigned long long sm = __ballot(searching);
             if (sm == 0ull) break;
             if (__popcll(sm) < tune.minSearch && __ballot(active && ref < 0) != 0ull) break;   // keep the leaf phase dense
+            const unsigned long long tI_ = STATS ? clock64() : 0ull;
             if (STATS && lane == 0) { st_[3]++; st_[4] += (unsigned long long)__popcll(sm); }
             if (searching) {
                 if (STATS) st_[0]++;
@@ -374,8 +394,10 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
                     } else pop_or_finish();
                 }
             }
+            if (STATS) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (lane == 0) st_[8] += clock64() - tI_; }
         }
         // ---- phase 2: leaves
+        const unsigned long long tL_ = STATS ? clock64() : 0ull;
         if (STATS) { unsigned long long lm = __ballot(active && ref < 0); if (lane == 0 && lm) { st_[5]++; st_[6] += (unsigned long long)__popcll(lm); } }
         if (active && ref < 0) {
             if (STATS) st_[1]++;
@@ -406,9 +428,11 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
                 active = false;
             } else pop_or_finish();
         }
+        if (STATS && lane == 0) st_[9] += clock64() - tL_;
     }
+    if (STATS && lane == 0) st_[11] = clock64() - tStart_;
     if (STATS && stats) {
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < 12; ++q) {
             unsigned long long v = st_[q];
             for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
             if (lane == 0 && v) atomicAdd(&stats[q], v);
@@ -652,7 +676,7 @@ struct RtWave {
     std::string err;
     int cus = 256;
     size_t budgetBytes = (size_t)8 << 30;   // ray-queue budget per context; 288 GB of HBM make this cheap
-    TraceTune tune{32, 16, 64, 2};
+    TraceTune tune{32, 16, 64, 2, 0};
     // allocations
     size_t slotsCap = 0;      // per-frame arrays sized for this many pixel slots
     size_t chunkBytes = 0;    // bytes of the per-chunk arena
@@ -670,7 +694,8 @@ RtWave *rt_wave_create(int cus) {
     w->cus = cus > 0 ? cus : 256;
     if (const char *e = getenv("RT_QUEUE_BUDGET_MB")) w->budgetBytes = (size_t)atoll(e) << 20;
     if (const char *e = getenv("RT_REFILL_MIN")) w->tune.refillMin = std::max(1, std::min(64, atoi(e)));
-    if (const char *e = getenv("RT_CHUNK")) w->tune.chunk = std::max(64, std::min(1 << 20, atoi(e)));
+    if (const char *e = getenv("RT_CHUNK")) w->tune.chunk = std::max(8, std::min(1 << 20, atoi(e)));
+    if (const char *e = getenv("RT_DEBUG_SKIP_TRAVERSAL")) w->tune.skipTraversal = atoi(e);
     if (const char *e = getenv("RT_OVERLAP")) w->overlap = atoi(e) != 0;
     if (const char *e = getenv("RT_LEAFB")) w->tune.leafb = atoi(e);
     if (const char *e = getenv("RT_MIN_SEARCH")) w->tune.minSearch = std::max(0, std::min(64, atoi(e)));
@@ -764,7 +789,7 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
     W_TRY(hipMemsetAsync(w->counts, 0, (size_t)(64 + nChunks) * sizeof(uint32_t), st));
     W_TRY(hipMemsetAsync(w->heads, 0, (size_t)(1 + nChunks * 3) * kHeadWords * sizeof(uint32_t), st));
     const int traceBlocks = w->cus;
-    if (getenv("RT_TRACE_STATS") && !w->stats) { W_TRY(hipMalloc(&w->stats, 32 * sizeof(unsigned long long))); W_TRY(hipMemset(w->stats, 0, 32 * sizeof(unsigned long long))); }
+    if (getenv("RT_TRACE_STATS") && !w->stats) { W_TRY(hipMalloc(&w->stats, 64 * sizeof(unsigned long long))); W_TRY(hipMemset(w->stats, 0, 64 * sizeof(unsigned long long))); }
     unsigned long long *S = w->stats;
     const TraceTune tune = w->tune;
     const unsigned tiles = (unsigned)std::max(host.g.nLocalTiles, 0);
@@ -794,21 +819,23 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
         // The bounce branch (trace_gi -> gen_gi -> trace_gi_shadow) and the direct shadow traversal only share their
         // producer (gen_direct) and consumer (combine): the bounce branch runs on a second, higher-priority stream so that
         // its kernels fill the ramp-down tails of the persistent traversal grids instead of waiting behind them.
-        hipStream_t sg = (w->overlap && u.enableGI == 1) ? w->side : st;
+        // measured: no gain when one GPU renders the whole frame (the traversal grids saturate it), ~5 % when the frame is
+        // split over ranks and every stage is latency-bound
+        hipStream_t sg = ((w->overlap || host.g.world > 1) && u.enableGI == 1) ? w->side : st;
         if (sg != st) { W_TRY(hipEventRecord(w->evFork, st)); W_TRY(hipStreamWaitEvent(sg, w->evFork, 0)); }
         if (u.enableGI == 1) {
             QueueSrc qg;
             qg.o = wb.giO; qg.d = wb.giD; qg.tm = wb.giL; qg.liveCount = &wb.counts[1]; qg.c0 = c0; qg.cap = wb.CH; qg.stride = wb.CH; qg.slots = (uint32_t)SPP;
             qg.outT = wb.giT; qg.outTri = wb.giTri; qg.outOcc = nullptr;
             rt_stage_begin(ctx, ST_TRACE_GI, sg);
-            launch_trace<QueueSrc, false>(sg, traceBlocks, treeDepth, dFrame, host.sc, qg, &wb.heads[(size_t)(1 + c * 3 + 1) * kHeadWords], &wb.counts[4], tune, S ? S + 16 : nullptr);
+            launch_trace<QueueSrc, false>(sg, traceBlocks, treeDepth, dFrame, host.sc, qg, &wb.heads[(size_t)(1 + c * 3 + 1) * kHeadWords], &wb.counts[4], tune, S ? S + 32 : nullptr);
             rt_stage_end(ctx, ST_TRACE_GI, 1, sg);
         }
         QueueSrc q1;
         q1.o = wb.shO; q1.d = wb.shD; q1.tm = wb.shT; q1.liveCount = &wb.counts[1]; q1.c0 = c0; q1.cap = wb.CH; q1.stride = wb.CH; q1.slots = (uint32_t)S1;
         q1.outT = nullptr; q1.outTri = nullptr; q1.outOcc = wb.occ1;
         rt_stage_begin(ctx, ST_TRACE_SHADOW);
-        launch_trace<QueueSrc, true>(st, traceBlocks, treeDepth, dFrame, host.sc, q1, &wb.heads[(size_t)(1 + c * 3 + 0) * kHeadWords], &wb.counts[3], tune, S ? S + 8 : nullptr);
+        launch_trace<QueueSrc, true>(st, traceBlocks, treeDepth, dFrame, host.sc, q1, &wb.heads[(size_t)(1 + c * 3 + 0) * kHeadWords], &wb.counts[3], tune, S ? S + 16 : nullptr);
         rt_stage_end(ctx, ST_TRACE_SHADOW, 1);
         if (u.enableGI == 1) {
             rt_stage_begin(ctx, ST_GEN_GI, sg);
@@ -819,7 +846,7 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
             q2.o = wb.sh2O; q2.d = wb.sh2D; q2.tm = wb.sh2T; q2.liveCount = &wb.counts[64 + c]; q2.c0 = 0; q2.cap = wb.CH * (uint32_t)SPP; q2.stride = wb.CH * (uint32_t)SPP; q2.slots = 6u;
             q2.outT = nullptr; q2.outTri = nullptr; q2.outOcc = wb.occ2;
             rt_stage_begin(ctx, ST_TRACE_GI_SHADOW, sg);
-            launch_trace<QueueSrc, true>(sg, traceBlocks, treeDepth, dFrame, host.sc, q2, &wb.heads[(size_t)(1 + c * 3 + 2) * kHeadWords], &wb.counts[5], tune, S ? S + 24 : nullptr);
+            launch_trace<QueueSrc, true>(sg, traceBlocks, treeDepth, dFrame, host.sc, q2, &wb.heads[(size_t)(1 + c * 3 + 2) * kHeadWords], &wb.counts[5], tune, S ? S + 48 : nullptr);
             rt_stage_end(ctx, ST_TRACE_GI_SHADOW, 1, sg);
         }
         if (sg != st) { W_TRY(hipEventRecord(w->evJoin, sg)); W_TRY(hipStreamWaitEvent(st, w->evJoin, 0)); }
@@ -838,14 +865,16 @@ int rt_wave_traced(RtWave *w, hipStream_t st, unsigned long long *out8, bool res
     W_TRY(hipStreamSynchronize(st));
     W_TRY(hipMemcpy(out8, w->acc, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     if (w->stats) {
-        unsigned long long v[32];
+        unsigned long long v[64];
         W_TRY(hipMemcpy(v, w->stats, sizeof v, hipMemcpyDeviceToHost));
         static const char *nm[4] = {"primary", "shadow", "bounce", "bounce_shadow"};
         for (int k = 0; k < 4; ++k) {
-            const unsigned long long *q = v + k * 8;
+            const unsigned long long *q = v + k * 16;
             double rays = (double)std::max<unsigned long long>(out8[2 + k], 1);
-            fprintf(stderr, "[trace stats] %-13s rays %.3g | per ray: inner %.1f leaf %.1f tri %.1f | inner-phase lane util %.2f (%.3g wave-iters) leaf-phase util %.2f (%.3g) | refill rounds %.3g\n",
-                    nm[k], rays, q[0] / rays, q[1] / rays, q[2] / rays, q[3] ? q[4] / (64.0 * q[3]) : 0.0, (double)q[3], q[5] ? q[6] / (64.0 * q[5]) : 0.0, (double)q[5], (double)q[7]);
+            fprintf(stderr, "[trace stats] %-13s rays %.3g | per ray: inner %.1f leaf %.1f tri %.1f | inner-phase lane util %.2f (%.3g wave-iters, %.0f cyc each) "
+                            "leaf-phase util %.2f (%.3g, %.0f cyc each) | refills %.3g (%.0f cyc each)\n",
+                    nm[k], rays, q[0] / rays, q[1] / rays, q[2] / rays, q[3] ? q[4] / (64.0 * q[3]) : 0.0, (double)q[3], q[3] ? (double)q[8] / q[3] : 0.0,
+                    q[5] ? q[6] / (64.0 * q[5]) : 0.0, (double)q[5], q[5] ? (double)q[9] / q[5] : 0.0, (double)q[7], q[7] ? (double)q[10] / q[7] : 0.0);
         }
         if (reset) W_TRY(hipMemset(w->stats, 0, sizeof v));
     }

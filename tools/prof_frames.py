@@ -14,6 +14,8 @@ ap.add_argument("--spp", type=int, default=4)
 ap.add_argument("--subdiv", type=int, default=6)
 ap.add_argument("--size", default="1920x1080")
 ap.add_argument("--scene", default="bunny")
+ap.add_argument("--world", type=int, default=1)
+ap.add_argument("--rank", type=int, default=0)
 a = ap.parse_args()
 W, H = map(int, a.size.split("x"))
 import time
@@ -26,7 +28,7 @@ faces = scenes.env_faces("Sky_01")
 p = rt.default_render_params(); p.sppPerFrame = a.spp
 cam = scenes.camera(a.camera, aspect=W / H)
 pipe = {"wave": rt.RT_PIPELINE_WAVEFRONT, "mega": rt.RT_PIPELINE_MEGAKERNEL}[a.pipeline]
-with rt.Renderer(pipeline=pipe) as r:
+with rt.Renderer(pipeline=pipe, rank=a.rank, world_size=a.world) as r:
     r.upload_bvh(nodes, tris); r.upload_env(faces); r.resize(W, H)
     for f in range(3):
         r.render_frame(rt.frame_uniforms(p, cam, W, H, f, True, nodes.shape[0], tris.shape[0]))
