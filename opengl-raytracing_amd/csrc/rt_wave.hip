@@ -202,6 +202,26 @@ struct QueueSrc {     // slot-major queue: ray r -> (slot = r / n, j = r % n) at
     RT_DEV void store_any(uint32_t a, bool occ) const { outOcc[a] = occ ? 1 : 0; }
 };
 
+// Two any-hit queues traced by ONE persistent launch (direct shadows + AO, then the shadows at the bounce hits): a second
+// launch would pay the ~0.15 ms ramp-up / drain latency of a persistent grid again for a few thousand rays.
+struct DualQueueSrc {
+    QueueSrc a, b;
+    uint32_t na;
+    RT_DEV void prepare() { a.prepare(); b.prepare(); na = a.size(); }
+    RT_DEV uint32_t size() const { return na + b.size(); }
+    RT_DEV bool load(uint32_t r, V3 &ro, V3 &rd, float &tMax, uint32_t &token) const {
+        if (r < na) return a.load(r, ro, rd, tMax, token);
+        bool live = b.load(r - na, ro, rd, tMax, token);
+        token |= 0x80000000u;             // results of the second queue (addresses stay below 2^31: checked on the host)
+        return live;
+    }
+    RT_DEV void store_closest(uint32_t, float, int) const {}
+    RT_DEV void store_any(uint32_t token, bool occ) const {
+        if (token & 0x80000000u) b.outOcc[token & 0x7fffffffu] = occ ? 1 : 0;
+        else a.outOcc[token] = occ ? 1 : 0;
+    }
+};
+
 // hipcc sinks loads into the branches that first use them (e.g. a triangle's v0 behind the determinant test), which turns
 // one gather round trip into two or three dependent ones.  pin() makes a loaded record "used" right after the loads were
 // issued, so the whole group is in flight together.
@@ -684,9 +704,6 @@ struct RtWave {
     uint32_t *counts = nullptr, *heads = nullptr;
     unsigned long long *acc = nullptr;   // traced-ray tallies accumulated over frames
     unsigned long long *stats = nullptr; // RT_TRACE_STATS=1: 4 stages x 8 diagnostic sums
-    hipStream_t side = nullptr;          // second stream for the bounce branch
-    hipEvent_t evFork = nullptr, evJoin = nullptr;
-    bool overlap = false;   // RT_OVERLAP=1: measured no wall-time gain on MI355X (the traversal grids already saturate the CUs)
 };
 
 RtWave *rt_wave_create(int cus) {
@@ -696,7 +713,6 @@ RtWave *rt_wave_create(int cus) {
     if (const char *e = getenv("RT_REFILL_MIN")) w->tune.refillMin = std::max(1, std::min(64, atoi(e)));
     if (const char *e = getenv("RT_CHUNK")) w->tune.chunk = std::max(8, std::min(1 << 20, atoi(e)));
     if (const char *e = getenv("RT_DEBUG_SKIP_TRAVERSAL")) w->tune.skipTraversal = atoi(e);
-    if (const char *e = getenv("RT_OVERLAP")) w->overlap = atoi(e) != 0;
     if (const char *e = getenv("RT_LEAFB")) w->tune.leafb = atoi(e);
     if (const char *e = getenv("RT_MIN_SEARCH")) w->tune.minSearch = std::max(0, std::min(64, atoi(e)));
     return w;
@@ -709,9 +725,6 @@ void rt_wave_destroy(RtWave *w) {
     if (w->heads) (void)hipFree(w->heads);
     if (w->acc) (void)hipFree(w->acc);
     if (w->stats) (void)hipFree(w->stats);
-    if (w->side) (void)hipStreamDestroy(w->side);
-    if (w->evFork) (void)hipEventDestroy(w->evFork);
-    if (w->evJoin) (void)hipEventDestroy(w->evJoin);
     delete w;
 }
 const char *rt_wave_error(const RtWave *w) { return w->err.c_str(); }
@@ -733,13 +746,6 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
     const int A = (u.enableAO == 1) ? std::max(u.aoSamples, 0) : 0;
     const int S1 = A + 6 * SPP, S2 = 6 * SPP;
 
-    if (!w->side) {
-        int lo = 0, hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // hi = numerically lowest = highest priority
-        W_TRY(hipStreamCreateWithPriority(&w->side, hipStreamNonBlocking, hi));
-        W_TRY(hipEventCreateWithFlags(&w->evFork, hipEventDisableTiming));
-        W_TRY(hipEventCreateWithFlags(&w->evJoin, hipEventDisableTiming));
-    }
     if (!w->counts) { W_TRY(hipMalloc(&w->counts, (64 + 4096) * sizeof(uint32_t))); W_TRY(hipMalloc(&w->heads, (size_t)kMaxLaunches * kHeadWords * sizeof(uint32_t)));
         W_TRY(hipMalloc(&w->acc, 8 * sizeof(unsigned long long))); W_TRY(hipMemsetAsync(w->acc, 0, 8 * sizeof(unsigned long long), st)); }
     // per-frame arena: cand, primT, primTri, hits
@@ -763,6 +769,7 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
         W_TRY(hipMalloc(&w->chunkArena, need));
         w->chunkBytes = need;
     }
+    if (CH * (size_t)std::max(S1, S2) >= ((size_t)1 << 31)) { w->err = "ray queue chunk exceeds 2^31 entries; lower RT_QUEUE_BUDGET_MB"; return RT_ERR_UNSUPPORTED; }
     WaveBuf wb;
     {
         char *p = (char *)w->frameArena;
@@ -816,40 +823,35 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
         hipLaunchKernelGGL(k_gen_direct, dim3(gridHS), dim3(256), 0, st, dFrame, wb, c0);
         rt_stage_end(ctx, ST_GEN_DIRECT, 1);
 
-        // The bounce branch (trace_gi -> gen_gi -> trace_gi_shadow) and the direct shadow traversal only share their
-        // producer (gen_direct) and consumer (combine): the bounce branch runs on a second, higher-priority stream so that
-        // its kernels fill the ramp-down tails of the persistent traversal grids instead of waiting behind them.
-        // measured: no gain when one GPU renders the whole frame (the traversal grids saturate it), ~5 % when the frame is
-        // split over ranks and every stage is latency-bound
-        hipStream_t sg = ((w->overlap || host.g.world > 1) && u.enableGI == 1) ? w->side : st;
-        if (sg != st) { W_TRY(hipEventRecord(w->evFork, st)); W_TRY(hipStreamWaitEvent(sg, w->evFork, 0)); }
-        if (u.enableGI == 1) {
-            QueueSrc qg;
-            qg.o = wb.giO; qg.d = wb.giD; qg.tm = wb.giL; qg.liveCount = &wb.counts[1]; qg.c0 = c0; qg.cap = wb.CH; qg.stride = wb.CH; qg.slots = (uint32_t)SPP;
-            qg.outT = wb.giT; qg.outTri = wb.giTri; qg.outOcc = nullptr;
-            rt_stage_begin(ctx, ST_TRACE_GI, sg);
-            launch_trace<QueueSrc, false>(sg, traceBlocks, treeDepth, dFrame, host.sc, qg, &wb.heads[(size_t)(1 + c * 3 + 1) * kHeadWords], &wb.counts[4], tune, S ? S + 32 : nullptr);
-            rt_stage_end(ctx, ST_TRACE_GI, 1, sg);
-        }
         QueueSrc q1;
         q1.o = wb.shO; q1.d = wb.shD; q1.tm = wb.shT; q1.liveCount = &wb.counts[1]; q1.c0 = c0; q1.cap = wb.CH; q1.stride = wb.CH; q1.slots = (uint32_t)S1;
         q1.outT = nullptr; q1.outTri = nullptr; q1.outOcc = wb.occ1;
-        rt_stage_begin(ctx, ST_TRACE_SHADOW);
-        launch_trace<QueueSrc, true>(st, traceBlocks, treeDepth, dFrame, host.sc, q1, &wb.heads[(size_t)(1 + c * 3 + 0) * kHeadWords], &wb.counts[3], tune, S ? S + 16 : nullptr);
-        rt_stage_end(ctx, ST_TRACE_SHADOW, 1);
         if (u.enableGI == 1) {
-            rt_stage_begin(ctx, ST_GEN_GI, sg);
-            hipLaunchKernelGGL(k_gen_gi, dim3(gridHS), dim3(256), 0, sg, dFrame, wb, c0, &wb.counts[64 + c]);
-            rt_stage_end(ctx, ST_GEN_GI, 1, sg);
+            // bounce rays first, then ONE any-hit launch over both shadow queues
+            QueueSrc qg;
+            qg.o = wb.giO; qg.d = wb.giD; qg.tm = wb.giL; qg.liveCount = &wb.counts[1]; qg.c0 = c0; qg.cap = wb.CH; qg.stride = wb.CH; qg.slots = (uint32_t)SPP;
+            qg.outT = wb.giT; qg.outTri = wb.giTri; qg.outOcc = nullptr;
+            rt_stage_begin(ctx, ST_TRACE_GI);
+            launch_trace<QueueSrc, false>(st, traceBlocks, treeDepth, dFrame, host.sc, qg, &wb.heads[(size_t)(1 + c * 3 + 1) * kHeadWords], &wb.counts[4], tune, S ? S + 32 : nullptr);
+            rt_stage_end(ctx, ST_TRACE_GI, 1);
 
-            QueueSrc q2;
-            q2.o = wb.sh2O; q2.d = wb.sh2D; q2.tm = wb.sh2T; q2.liveCount = &wb.counts[64 + c]; q2.c0 = 0; q2.cap = wb.CH * (uint32_t)SPP; q2.stride = wb.CH * (uint32_t)SPP; q2.slots = 6u;
-            q2.outT = nullptr; q2.outTri = nullptr; q2.outOcc = wb.occ2;
-            rt_stage_begin(ctx, ST_TRACE_GI_SHADOW, sg);
-            launch_trace<QueueSrc, true>(sg, traceBlocks, treeDepth, dFrame, host.sc, q2, &wb.heads[(size_t)(1 + c * 3 + 2) * kHeadWords], &wb.counts[5], tune, S ? S + 48 : nullptr);
-            rt_stage_end(ctx, ST_TRACE_GI_SHADOW, 1, sg);
+            rt_stage_begin(ctx, ST_GEN_GI);
+            hipLaunchKernelGGL(k_gen_gi, dim3(gridHS), dim3(256), 0, st, dFrame, wb, c0, &wb.counts[64 + c]);
+            rt_stage_end(ctx, ST_GEN_GI, 1);
+
+            DualQueueSrc qq;
+            qq.a = q1;
+            qq.b.o = wb.sh2O; qq.b.d = wb.sh2D; qq.b.tm = wb.sh2T; qq.b.liveCount = &wb.counts[64 + c]; qq.b.c0 = 0; qq.b.cap = wb.CH * (uint32_t)SPP;
+            qq.b.stride = wb.CH * (uint32_t)SPP; qq.b.slots = 6u;
+            qq.b.outT = nullptr; qq.b.outTri = nullptr; qq.b.outOcc = wb.occ2;
+            rt_stage_begin(ctx, ST_TRACE_SHADOW);
+            launch_trace<DualQueueSrc, true>(st, traceBlocks, treeDepth, dFrame, host.sc, qq, &wb.heads[(size_t)(1 + c * 3 + 0) * kHeadWords], &wb.counts[3], tune, S ? S + 16 : nullptr);
+            rt_stage_end(ctx, ST_TRACE_SHADOW, 1);
+        } else {
+            rt_stage_begin(ctx, ST_TRACE_SHADOW);
+            launch_trace<QueueSrc, true>(st, traceBlocks, treeDepth, dFrame, host.sc, q1, &wb.heads[(size_t)(1 + c * 3 + 0) * kHeadWords], &wb.counts[3], tune, S ? S + 16 : nullptr);
+            rt_stage_end(ctx, ST_TRACE_SHADOW, 1);
         }
-        if (sg != st) { W_TRY(hipEventRecord(w->evJoin, sg)); W_TRY(hipStreamWaitEvent(st, w->evJoin, 0)); }
         rt_stage_begin(ctx, ST_COMBINE);
         hipLaunchKernelGGL(k_combine, dim3(gridH), dim3(256), 0, st, dFrame, tg, wb, c0);
         rt_stage_end(ctx, ST_COMBINE, 1);
