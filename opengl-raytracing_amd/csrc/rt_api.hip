@@ -23,7 +23,10 @@ struct StageEvent { int stage; hipEvent_t a, b; };
 
 struct RtContext {
     RtDeviceConfig cfg{};
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;        // lane 0 (even frames) and every non-frame operation
+    hipStream_t stream2 = nullptr;       // lane 1 (odd frames): consecutive frames overlap up to the temporal resolve
+    hipStream_t lastStream = nullptr;    // stream of the most recent frame (gather / assemble are ordered behind it)
+    hipEvent_t evDone[2] = {nullptr, nullptr};   // frame on lane i has written its targets
     std::string err;
     // scene
     float4 *dWNodes = nullptr, *dW4 = nullptr, *dTris = nullptr;
@@ -41,11 +44,11 @@ struct RtContext {
     int frameIndex = 0, writeIdx = 0;     // include/render/accum.h:125-138
     bool haveFrameState = false;
     float prevVP[16];
-    DevFrame *dFrame = nullptr;
+    DevFrame *dFrame[2] = {nullptr, nullptr};
     unsigned long long *dCounters = nullptr;
     void *dStaging = nullptr;
     size_t stagingBytes = 0;
-    RtWave *wave = nullptr;
+    RtWave *wave[2] = {nullptr, nullptr};
     // timing
     bool timing = false;
     std::vector<StageEvent> pending;
@@ -64,6 +67,11 @@ static int fail(RtContext *c, int code, const char *fmt, ...) {
     if (c) c->err = buf; else g_createError = buf;
     return code;
 }
+static hipError_t sync_all(RtContext *c) {
+    hipError_t e = hipStreamSynchronize(c->stream);
+    hipError_t e2 = c->stream2 ? hipStreamSynchronize(c->stream2) : hipSuccess;
+    return e != hipSuccess ? e : e2;
+}
 #define HIP_TRY(c, expr)                                                                                  \
     do {                                                                                                  \
         hipError_t e_ = (expr);                                                                           \
@@ -71,7 +79,7 @@ static int fail(RtContext *c, int code, const char *fmt, ...) {
     } while (0)
 
 static const char *kStageNames[RT_MAX_STAGES] = {"mega",     "primary", "trace_primary",   "post_primary", "gen_direct", "trace_shadow",
-                                                 "trace_gi", "gen_gi",  "trace_gi_shadow", "combine",      "assemble",   "present"};
+                                                 "trace_gi", "gen_gi",  "resolve",         "combine",      "assemble",   "present"};
 
 // ------------------------------------------------------------------------------------------------
 namespace {
@@ -217,7 +225,7 @@ void rt_stage_end(RtContext *c, int stage, int launches, hipStream_t on) {
     c->stageLaunches[stage] += (uint64_t)launches;
 }
 static void resolve_stage_events(RtContext *c) {
-    (void)hipStreamSynchronize(c->stream);
+    (void)sync_all(c);
     for (auto &ev : c->pending) {
         float ms = 0.0f;
         if (hipEventElapsedTime(&ms, ev.a, ev.b) == hipSuccess) c->stageMs[ev.stage] += ms;
@@ -250,13 +258,17 @@ int rt_create(const RtDeviceConfig *cfg, RtContext **out) {
         return fail(nullptr, RT_ERR_UNSUPPORTED, "rt_create: device is %s, this library carries gfx950 code only", prop.gcnArchName);
     RtContext *c = new RtContext();
     c->cfg = *cfg;
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipMalloc(&c->dFrame, sizeof(DevFrame)) != hipSuccess ||
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc(&c->dFrame[0], sizeof(DevFrame)) != hipSuccess || hipMalloc(&c->dFrame[1], sizeof(DevFrame)) != hipSuccess ||
+        hipEventCreateWithFlags(&c->evDone[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->evDone[1], hipEventDisableTiming) != hipSuccess ||
         hipMalloc(&c->dCounters, 8 * sizeof(unsigned long long)) != hipSuccess) {
         delete c;
         return fail(nullptr, RT_ERR_HIP, "rt_create: stream/alloc failed");
     }
     (void)hipMemset(c->dCounters, 0, 8 * sizeof(unsigned long long));
-    c->wave = rt_wave_create(prop.multiProcessorCount);
+    c->wave[0] = rt_wave_create(prop.multiProcessorCount);
+    c->wave[1] = rt_wave_create(prop.multiProcessorCount);
+    c->lastStream = c->stream;
     int rc = rt_upload_env(c, nullptr, 0, 0);   // dummy cube map like Application::initState (application.cpp:281)
     if (rc != RT_OK) { g_createError = c->err; rt_destroy(c); return rc; }
     *out = c;
@@ -266,14 +278,14 @@ int rt_create(const RtDeviceConfig *cfg, RtContext **out) {
 void rt_destroy(RtContext *c) {
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->stream) (void)sync_all(c);
     free_targets(c);
-    if (c->wave) rt_wave_destroy(c->wave);
+    for (int i = 0; i < 2; ++i) { if (c->wave[i]) rt_wave_destroy(c->wave[i]); if (c->dFrame[i]) (void)hipFree(c->dFrame[i]); if (c->evDone[i]) (void)hipEventDestroy(c->evDone[i]); }
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->dWNodes) (void)hipFree(c->dWNodes);
     if (c->dW4) (void)hipFree(c->dW4);
     if (c->dTris) (void)hipFree(c->dTris);
     if (c->dEnv) (void)hipFree(c->dEnv);
-    if (c->dFrame) (void)hipFree(c->dFrame);
     if (c->dCounters) (void)hipFree(c->dCounters);
     if (c->dStaging) (void)hipFree(c->dStaging);
     for (auto &ev : c->pending) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
@@ -286,7 +298,7 @@ int rt_upload_bvh(RtContext *c, const float *nodes12, int nNodes, const float *t
     if (!c) return RT_ERR_INVALID;
     if (nNodes < 0 || nTris < 0 || (nNodes > 0 && !nodes12) || (nTris > 0 && !tris12)) return fail(c, RT_ERR_INVALID, "rt_upload_bvh: bad arguments");
     (void)hipSetDevice(c->cfg.device);
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, sync_all(c));
     if (c->dWNodes) (void)hipFree(c->dWNodes);
     if (c->dW4) (void)hipFree(c->dW4);
     if (c->dTris) (void)hipFree(c->dTris);
@@ -418,7 +430,7 @@ int rt_upload_env(RtContext *c, const uint8_t *faces, int faceSize, int channels
         rgba[i * 4 + 2] = faces[i * channels + 2];
         rgba[i * 4 + 3] = (channels == 4) ? faces[i * channels + 3] : (uint8_t)255;
     }
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, sync_all(c));
     if (c->dEnv) (void)hipFree(c->dEnv);
     c->dEnv = nullptr;
     HIP_TRY(c, hipMalloc(&c->dEnv, texels * 4));
@@ -431,7 +443,7 @@ int rt_resize(RtContext *c, int w, int h) {
     if (!c) return RT_ERR_INVALID;
     if (w <= 0 || h <= 0) return fail(c, RT_ERR_INVALID, "rt_resize: %dx%d", w, h);
     (void)hipSetDevice(c->cfg.device);
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, sync_all(c));
     free_targets(c);
     FrameGeom g;
     g.W = w; g.H = h;
@@ -458,6 +470,7 @@ int rt_reset_accum(RtContext *c) {
     if (!c) return RT_ERR_INVALID;
     if (!c->sized) return fail(c, RT_ERR_STATE, "rt_reset_accum before rt_resize");
     (void)hipSetDevice(c->cfg.device);
+    HIP_TRY(c, sync_all(c));
     c->frameIndex = 0;
     c->writeIdx = 0;
     for (int i = 0; i < 2; ++i) HIP_TRY(c, hipMemsetAsync(c->dColor[i], 0, c->nSlots * 8, c->stream));
@@ -486,7 +499,12 @@ int rt_render_frame(RtContext *c, const RtUniforms *uIn) {
     fr.sc = make_dev_scene(c);
     if (!(fr.u.nodeCount > 0 && fr.u.triCount > 0)) fr.sc.hasBVH = 0;
     fr.g = c->g;
-    HIP_TRY(c, hipMemcpyAsync(c->dFrame, &fr, sizeof(fr), hipMemcpyHostToDevice, c->stream));
+    // Lane = parity of the frame index = index of the COLOR0 buffer this frame writes: consecutive frames alternate between
+    // two streams and overlap everywhere except at the temporal resolve (the only read of the previous frame), and every
+    // later reader of a COLOR0 buffer (gather, assemble) is stream-ordered before the next writer of the same buffer.
+    const int lane = c->writeIdx;
+    hipStream_t st = lane ? c->stream2 : c->stream;
+    HIP_TRY(c, hipMemcpyAsync(c->dFrame[lane], &fr, sizeof(fr), hipMemcpyHostToDevice, st));
     Targets tg;
     tg.color = c->dColor[c->writeIdx];
     tg.prev = c->dColor[1 - c->writeIdx];
@@ -496,13 +514,16 @@ int rt_render_frame(RtContext *c, const RtUniforms *uIn) {
     if (pipeline == RT_PIPELINE_AUTO) pipeline = (fr.u.useBVH == 1 && fr.sc.hasBVH && !count) ? RT_PIPELINE_WAVEFRONT : RT_PIPELINE_MEGAKERNEL;
     if (pipeline == RT_PIPELINE_WAVEFRONT && !(fr.u.useBVH == 1)) pipeline = RT_PIPELINE_MEGAKERNEL;   // analytic scene: pure ALU, megakernel only
     if (pipeline == RT_PIPELINE_WAVEFRONT) {
-        int rc = rt_wave_render(c->wave, c, c->stream, c->dFrame, fr, tg, c->dCounters, count, std::max(c->treeDepth, 1));
-        if (rc != RT_OK) return fail(c, rc, "wavefront pipeline: %s", rt_wave_error(c->wave));
+        int rc = rt_wave_render(c->wave[lane], c, st, c->dFrame[lane], fr, tg, c->dCounters, count, std::max(c->treeDepth, 1), c->evDone[1 - lane]);
+        if (rc != RT_OK) return fail(c, rc, "wavefront pipeline: %s", rt_wave_error(c->wave[lane]));
     } else {
-        rt_stage_begin(c, 0);
-        HIP_TRY(c, rtl::launch_mega(c->stream, c->dFrame, tg, c->dCounters, count, std::max(c->treeDepth, 1), c->g.nLocalTiles));
-        rt_stage_end(c, 0, 1);
+        HIP_TRY(c, hipStreamWaitEvent(st, c->evDone[1 - lane], 0));   // the megakernel reads the history from its first instruction on
+        rt_stage_begin(c, 0, st);
+        HIP_TRY(c, rtl::launch_mega(st, c->dFrame[lane], tg, c->dCounters, count, std::max(c->treeDepth, 1), c->g.nLocalTiles));
+        rt_stage_end(c, 0, 1, st);
     }
+    HIP_TRY(c, hipEventRecord(c->evDone[lane], st));
+    c->lastStream = st;
     if (c->timing) c->timedFrames++;
     c->frameIndex++;                 // Accum::swapAfterFrame, include/render/accum.h:125-128
     c->writeIdx = 1 - c->writeIdx;
@@ -531,7 +552,7 @@ int rt_render_ray(RtContext *c, const RtRenderParams *params, const RtCamera *ca
 int rt_synchronize(RtContext *c) {
     if (!c) return RT_ERR_INVALID;
     (void)hipSetDevice(c->cfg.device);
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, sync_all(c));
     return RT_OK;
 }
 
@@ -543,12 +564,13 @@ int rt_read_target(RtContext *c, int which, void *dst, int fmt) {
     void *src = target_ptr(c, which, ch);
     if (!src || (fmt != RT_FORMAT_F16 && fmt != RT_FORMAT_F32)) return fail(c, RT_ERR_INVALID, "rt_read_target: which=%d format=%d", which, fmt);
     const size_t n = (size_t)c->g.W * c->g.H, bytes = n * ch * (fmt == RT_FORMAT_F32 ? 4 : 2);
+    HIP_TRY(c, sync_all(c));
     int rc = ensure_staging(c, bytes);
     if (rc != RT_OK) return rc;
     hipLaunchKernelGGL(k_untile, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, src, c->dStaging, c->g, ch, fmt == RT_FORMAT_F32 ? 1 : 0);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(dst, c->dStaging, bytes, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, sync_all(c));
     return RT_OK;
 }
 
@@ -559,13 +581,14 @@ int rt_present(RtContext *c, const RtPresentParams *p, uint8_t *dst) {
     if ((int)p->resolution[0] != c->g.W || (int)p->resolution[1] != c->g.H) return fail(c, RT_ERR_INVALID, "rt_present: uResolution != framebuffer");
     (void)hipSetDevice(c->cfg.device);
     const size_t bytes = (size_t)c->g.W * c->g.H * 4;
+    HIP_TRY(c, sync_all(c));
     int rc = ensure_staging(c, bytes);
     if (rc != RT_OK) return rc;
     rt_stage_begin(c, 11);
     HIP_TRY(c, rtl::launch_present(c->stream, c->g, c->dColor[1 - c->writeIdx], c->dMotion, c->dGPos, c->dGNrm, *p, (uint32_t *)c->dStaging));
     rt_stage_end(c, 11, 1);
     HIP_TRY(c, hipMemcpyAsync(dst, c->dStaging, bytes, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, sync_all(c));
     return RT_OK;
 }
 
@@ -591,15 +614,16 @@ int rt_assemble_gathered(RtContext *c, int which, const void *gatheredDev, void 
     (void)hipSetDevice(c->cfg.device);
     const int ch = (which == RT_TARGET_MOTION) ? 2 : 4;
     const size_t n = (size_t)c->g.W * c->g.H;
-    rt_stage_begin(c, 10);
-    hipLaunchKernelGGL(k_assemble, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, gatheredDev, dstDev, c->g, ch, c->nSlots * ch * 2);
-    rt_stage_end(c, 10, 1);
+    hipStream_t st = c->lastStream ? c->lastStream : c->stream;   // behind the gather the caller enqueued on rt_stream()
+    rt_stage_begin(c, 10, st);
+    hipLaunchKernelGGL(k_assemble, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, gatheredDev, dstDev, c->g, ch, c->nSlots * ch * 2);
+    rt_stage_end(c, 10, 1, st);
     HIP_TRY(c, hipGetLastError());
     return RT_OK;
 }
 int rt_stream(RtContext *c, void **s) {
     if (!c || !s) return RT_ERR_INVALID;
-    *s = (void *)c->stream;
+    *s = (void *)(c->lastStream ? c->lastStream : c->stream);   // the stream the most recent frame was enqueued on
     return RT_OK;
 }
 
@@ -608,7 +632,7 @@ int rt_get_counters(RtContext *c, RtCounters *out) {
     if (!c->cfg.countWork) return fail(c, RT_ERR_STATE, "rt_get_counters: context created without countWork");
     (void)hipSetDevice(c->cfg.device);
     unsigned long long v[8];
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, sync_all(c));
     HIP_TRY(c, hipMemcpy(v, c->dCounters, sizeof v, hipMemcpyDeviceToHost));
     out->raysClosest = v[0]; out->raysShadow = v[1]; out->raysAnalytic = v[2]; out->nodeFetch = v[3];
     out->triFetch = v[4]; out->envLookup = v[5]; out->hitPixels = v[6];
@@ -624,9 +648,14 @@ int rt_reset_counters(RtContext *c) {
 int rt_get_traced_rays(RtContext *c, RtTracedRays *out, int reset) {
     if (!c || !out) return RT_ERR_INVALID;
     (void)hipSetDevice(c->cfg.device);
-    unsigned long long v[8];
-    int rc = rt_wave_traced(c->wave, c->stream, v, reset != 0);
-    if (rc != RT_OK) return fail(c, rc, "rt_get_traced_rays: %s", rt_wave_error(c->wave));
+    unsigned long long v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    (void)sync_all(c);
+    for (int i = 0; i < 2; ++i) {
+        unsigned long long t[8];
+        int rc = rt_wave_traced(c->wave[i], i ? c->stream2 : c->stream, t, reset != 0);
+        if (rc != RT_OK) return fail(c, rc, "rt_get_traced_rays: %s", rt_wave_error(c->wave[i]));
+        for (int k = 0; k < 8; ++k) v[k] += t[k];
+    }
     out->candidatePixels = v[0]; out->hitPixels = v[1]; out->primary = v[2]; out->shadow = v[3]; out->bounce = v[4];
     out->bounceShadow = v[5]; out->frames = v[6];
     return RT_OK;
@@ -665,7 +694,7 @@ int rt_debug_eval(RtContext *c, int op, const float *a, const float *b, const fl
     if (cc) { HIP_TRY(c, hipMalloc(&dc, bytes)); HIP_TRY(c, hipMemcpy(dc, cc, bytes, hipMemcpyHostToDevice)); }
     hipLaunchKernelGGL(k_debug_eval, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, op, da, db, dc, dout, n);
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, sync_all(c));
     HIP_TRY(c, hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost));
     (void)hipFree(da); (void)hipFree(dout);
     if (db) (void)hipFree(db);
@@ -687,7 +716,7 @@ int rt_debug_trace(RtContext *c, int kind, const float *origins, const float *di
     DevScene sc = make_dev_scene(c);
     hipLaunchKernelGGL(k_debug_trace, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, sc, kind, dO, dD, dT, eps, inf, dOut, n);
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, sync_all(c));
     HIP_TRY(c, hipMemcpy(out7, dOut, (size_t)n * 28, hipMemcpyDeviceToHost));
     (void)hipFree(dO); (void)hipFree(dD); (void)hipFree(dT); (void)hipFree(dOut);
     return RT_OK;

@@ -41,7 +41,7 @@
 using namespace rtd;
 
 // stage ids (rt_stage_name in rt_api.hip)
-enum { ST_PRIMARY = 1, ST_TRACE_PRIMARY, ST_POST_PRIMARY, ST_GEN_DIRECT, ST_TRACE_SHADOW, ST_TRACE_GI, ST_GEN_GI, ST_TRACE_GI_SHADOW, ST_COMBINE };
+enum { ST_PRIMARY = 1, ST_TRACE_PRIMARY, ST_POST_PRIMARY, ST_GEN_DIRECT, ST_TRACE_SHADOW, ST_TRACE_GI, ST_GEN_GI, ST_RESOLVE, ST_COMBINE };
 
 struct HitRec { uint32_t slot; float t; int tri; };
 
@@ -63,6 +63,10 @@ struct WaveBuf {
     float4 *sh2O, *sh2D;     // shadow queue 2: 6 slots x (CH*SPP), entries compacted over the (hit, sample) pairs whose bounce hit
     uint8_t *occ2;
     int *giPos;              // per (sample, hit): entry in queue 2, -1 when the bounce ray missed or was not cast
+    // per frame, per pixel slot: everything the frame produced BEFORE the temporal resolve (the only history-dependent step)
+    float4 *pendC;           // curr.rgb (frame average, fp32), motion.x
+    float *pendMy;           // motion.y
+    uint2 *pendPos, *pendNrm;
     uint32_t CH;             // chunk capacity (hits)
     int A;                   // AO rays per hit (0 when AO is off)
     int SPP;
@@ -71,22 +75,37 @@ struct WaveBuf {
 namespace {
 
 
-// ---- finishing a pixel: frame average -> TAA -> 4 targets (rt.frag:184-196) -------------------
-RT_DEV void finish_pixel(const DevFrame *fr, const Targets &tg, int slot, int px, int py, V3 frameSum, V2 motionOut, V4 gpos, V4 gnrm) {
-    const RtUniforms &u = fr->u;
-    const int SPP = max(u.spp, 1);
+// ---- finishing a pixel.  rt.frag:184-196 = frame average -> TAA resolve against the history -> 4 target stores.  The history
+// read is the ONLY dependency of a frame on its predecessor, so the stages stash the pre-resolve values and a final k_resolve
+// does TAA + stores.  Frames f and f+1 run on two streams and overlap everywhere except resolve(f) -> resolve(f+1), which
+// keeps the GPU busy when one frame's stages are latency-bound (tile-parallel ranks with 1/8 of the pixels, small frames).
+RT_DEV void finish_pixel(const DevFrame *fr, const WaveBuf &wb, int slot, V3 frameSum, V2 motionOut, V4 gpos, V4 gnrm) {
+    const int SPP = max(fr->u.spp, 1);
     V3 curr = frameSum / (float)SPP;
-    float uvx = ((float)px + 0.5f) / (float)fr->g.W, uvy = ((float)py + 0.5f) / (float)fr->g.H;
+    wb.pendC[slot] = make_float4(curr.x, curr.y, curr.z, motionOut.x);
+    wb.pendMy[slot] = motionOut.y;
+    wb.pendPos[slot] = pack_half4(gpos);
+    wb.pendNrm[slot] = pack_half4(gnrm);
+}
+__global__ __launch_bounds__(256) void k_resolve(const DevFrame *__restrict__ fr, Targets tg, WaveBuf wb) {
+    const RtUniforms &u = fr->u;
+    int px, py;
+    if (!pixel_of_slot(fr->g, blockIdx.x, threadIdx.x, px, py)) return;
+    const int slot = blockIdx.x * 256 + threadIdx.x;
+    float4 pc = wb.pendC[slot];
+    V3 curr = mk3(pc.x, pc.y, pc.z);
+    V2 motionOut = mk2(pc.w, wb.pendMy[slot]);
+    float uvx = ((float)px + 0.5f) / (float)fr->g.W, uvy = ((float)py + 0.5f) / (float)fr->g.H;   // rt_fullscreen.vert:44
     V2 taaMotion = (u.cameraMoved == 1) ? motionOut : mk2(0.0f, 0.0f);
     HistoryTex hist;
     hist.prev = tg.prev; hist.g = &fr->g; hist.slot = slot;
     V4 taa = resolveTAA(u, curr, uvx, uvy, taaMotion, u.frameIndex, hist);
     tg.color[slot] = pack_half4(taa);
     tg.motion[slot] = pack_half2(motionOut);
-    tg.gpos[slot] = pack_half4(gpos);
-    tg.gnrm[slot] = pack_half4(gnrm);
+    tg.gpos[slot] = wb.pendPos[slot];
+    tg.gnrm[slot] = wb.pendNrm[slot];
 }
-RT_DEV void finish_miss(const DevFrame *fr, const Targets &tg, int slot, int px, int py, V3 dir) {
+RT_DEV void finish_miss(const DevFrame *fr, const WaveBuf &wb, int slot, int px, int py, V3 dir) {
     const RtUniforms &u = fr->u;
     Frag F;
     F.u = &u; F.sc = &fr->sc; F.fcx = (float)px + 0.5f; F.fcy = (float)py + 0.5f;
@@ -96,7 +115,7 @@ RT_DEV void finish_miss(const DevFrame *fr, const Targets &tg, int slot, int px,
     const int SPP = max(u.spp, 1);
     for (int s = 0; s < SPP; ++s) frameSum = frameSum + r;   // the reference adds the same radiance SPP times
     V2 motionOut = (u.cameraMoved == 1) ? mk2(4.0f, 4.0f) : mk2(0.0f, 0.0f);
-    finish_pixel(fr, tg, slot, px, py, frameSum, motionOut, mk4(0, 0, 0, 0), mk4(0, 0, 0, 0));
+    finish_pixel(fr, wb, slot, frameSum, motionOut, mk4(0, 0, 0, 0), mk4(0, 0, 0, 0));
 }
 RT_DEV void slot_to_pixel(const FrameGeom &g, uint32_t slot, int &px, int &py) { pixel_of_slot(g, (int)(slot >> 8), (int)(slot & 255u), px, py); }
 
@@ -148,7 +167,7 @@ __global__ __launch_bounds__(256) void k_primary(const DevFrame *__restrict__ fr
         V3 rdInv = mk3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
         float tmin;
         cand = fr->sc.hasBVH && slab(ld3(u.camPos), rdInv, ld3(fr->sc.rootMin), ld3(fr->sc.rootMax), tmin) && !(tmin > u.inf);
-        if (!cand) finish_miss(fr, tg, slot, px, py, dir);
+        if (!cand) finish_miss(fr, wb, slot, px, py, dir);
     }
     uint32_t idx = block_append(cand, &wb.counts[0]);
     if (cand) wb.cand[idx] = (uint32_t)slot;
@@ -481,7 +500,7 @@ __global__ __launch_bounds__(256) void k_post_primary(const DevFrame *__restrict
         if (!hit) {
             int px, py;
             slot_to_pixel(fr->g, slot, px, py);
-            finish_miss(fr, tg, (int)slot, px, py, primaryDir(fr->u, (float)px + 0.5f, (float)py + 0.5f));
+            finish_miss(fr, wb, (int)slot, px, py, primaryDir(fr->u, (float)px + 0.5f, (float)py + 0.5f));
         }
     }
     uint32_t idx = block_append(hit, &wb.counts[1]);
@@ -656,7 +675,7 @@ __global__ __launch_bounds__(256) void k_combine(const DevFrame *__restrict__ fr
         int seed = (int)((uint32_t)u.frameIndex * (uint32_t)SPP + (uint32_t)s);
         frameSum = frameSum + shadeSampleBVH<CombineTracer, false>(tr, c.F, c.hp, c.hn, -c.dir, seed, ao, w);
     }
-    finish_pixel(fr, tg, (int)c.slot, c.px, c.py, frameSum, motionOut, mk4(c.hp.x, c.hp.y, c.hp.z, 1.0f), mk4(nn.x, nn.y, nn.z, 0.0f));
+    finish_pixel(fr, wb, (int)c.slot, frameSum, motionOut, mk4(c.hp.x, c.hp.y, c.hp.z, 1.0f), mk4(nn.x, nn.y, nn.z, 0.0f));
 }
 
 __global__ void k_accum_tally(const uint32_t *counts, unsigned long long *acc) {
@@ -738,7 +757,7 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
     } while (0)
 
 int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dFrame, const DevFrame &host, Targets tg,
-                   unsigned long long *, bool count, int treeDepth) {
+                   unsigned long long *, bool count, int treeDepth, hipEvent_t evPrevDone) {
     if (count) { w->err = "work counters are produced by the megakernel pipeline (RT_PIPELINE_MEGAKERNEL)"; return RT_ERR_UNSUPPORTED; }
     const RtUniforms &u = host.u;
     const size_t nSlots = (size_t)std::max(host.g.nLocalTiles, 1) * 256;
@@ -752,7 +771,7 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
     if (w->slotsCap < nSlots) {
         if (w->frameArena) (void)hipFree(w->frameArena);
         w->frameArena = nullptr;
-        W_TRY(hipMalloc(&w->frameArena, nSlots * (4 + 4 + 4 + sizeof(HitRec))));
+        W_TRY(hipMalloc(&w->frameArena, nSlots * (4 + 4 + 4 + sizeof(HitRec) + 16 + 4 + 8 + 8)));
         w->slotsCap = nSlots;
     }
     // chunk capacity from the budget
@@ -776,7 +795,11 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
         wb.cand = (uint32_t *)p; p += nSlots * 4;
         wb.primT = (float *)p; p += nSlots * 4;
         wb.primTri = (int *)p; p += nSlots * 4;
-        wb.hits = (HitRec *)p;
+        wb.hits = (HitRec *)p; p += nSlots * sizeof(HitRec);
+        wb.pendC = (float4 *)p; p += nSlots * 16;     // nSlots is a multiple of 256: every sub-array stays 16-byte aligned
+        wb.pendPos = (uint2 *)p; p += nSlots * 8;
+        wb.pendNrm = (uint2 *)p; p += nSlots * 8;
+        wb.pendMy = (float *)p;
         char *q = (char *)w->chunkArena;
         auto take = [&](size_t bytes) { char *r = q; q += align_up(bytes, 256); return r; };
         wb.shO = (float4 *)take(CH * (size_t)S1 * 16); wb.shD = (float4 *)take(CH * (size_t)S1 * 16);
@@ -802,26 +825,26 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
     const unsigned tiles = (unsigned)std::max(host.g.nLocalTiles, 0);
     if (tiles == 0) return RT_OK;
 
-    rt_stage_begin(ctx, ST_PRIMARY);
+    rt_stage_begin(ctx, ST_PRIMARY, st);
     hipLaunchKernelGGL(k_primary, dim3(tiles), dim3(256), 0, st, dFrame, tg, wb);
-    rt_stage_end(ctx, ST_PRIMARY, 1);
+    rt_stage_end(ctx, ST_PRIMARY, 1, st);
 
-    rt_stage_begin(ctx, ST_TRACE_PRIMARY);
+    rt_stage_begin(ctx, ST_TRACE_PRIMARY, st);
     PrimarySrc ps;
     ps.fr = dFrame; ps.cand = wb.cand; ps.count = &wb.counts[0]; ps.outT = wb.primT; ps.outTri = wb.primTri;
     launch_trace<PrimarySrc, false>(st, traceBlocks, treeDepth, dFrame, host.sc, ps, &wb.heads[0], &wb.counts[2], tune, S ? S + 0 : nullptr);
-    rt_stage_end(ctx, ST_TRACE_PRIMARY, 1);
+    rt_stage_end(ctx, ST_TRACE_PRIMARY, 1, st);
 
-    rt_stage_begin(ctx, ST_POST_PRIMARY);
+    rt_stage_begin(ctx, ST_POST_PRIMARY, st);
     hipLaunchKernelGGL(k_post_primary, dim3(tiles), dim3(256), 0, st, dFrame, tg, wb);
-    rt_stage_end(ctx, ST_POST_PRIMARY, 1);
+    rt_stage_end(ctx, ST_POST_PRIMARY, 1, st);
 
     for (int c = 0; c < nChunks; ++c) {
         const uint32_t c0 = (uint32_t)((size_t)c * CH);
         const unsigned gridHS = (unsigned)((CH * (size_t)SPP + 255) / 256), gridH = (unsigned)((CH + 255) / 256);
-        rt_stage_begin(ctx, ST_GEN_DIRECT);
+        rt_stage_begin(ctx, ST_GEN_DIRECT, st);
         hipLaunchKernelGGL(k_gen_direct, dim3(gridHS), dim3(256), 0, st, dFrame, wb, c0);
-        rt_stage_end(ctx, ST_GEN_DIRECT, 1);
+        rt_stage_end(ctx, ST_GEN_DIRECT, 1, st);
 
         QueueSrc q1;
         q1.o = wb.shO; q1.d = wb.shD; q1.tm = wb.shT; q1.liveCount = &wb.counts[1]; q1.c0 = c0; q1.cap = wb.CH; q1.stride = wb.CH; q1.slots = (uint32_t)S1;
@@ -831,32 +854,37 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
             QueueSrc qg;
             qg.o = wb.giO; qg.d = wb.giD; qg.tm = wb.giL; qg.liveCount = &wb.counts[1]; qg.c0 = c0; qg.cap = wb.CH; qg.stride = wb.CH; qg.slots = (uint32_t)SPP;
             qg.outT = wb.giT; qg.outTri = wb.giTri; qg.outOcc = nullptr;
-            rt_stage_begin(ctx, ST_TRACE_GI);
+            rt_stage_begin(ctx, ST_TRACE_GI, st);
             launch_trace<QueueSrc, false>(st, traceBlocks, treeDepth, dFrame, host.sc, qg, &wb.heads[(size_t)(1 + c * 3 + 1) * kHeadWords], &wb.counts[4], tune, S ? S + 32 : nullptr);
-            rt_stage_end(ctx, ST_TRACE_GI, 1);
+            rt_stage_end(ctx, ST_TRACE_GI, 1, st);
 
-            rt_stage_begin(ctx, ST_GEN_GI);
+            rt_stage_begin(ctx, ST_GEN_GI, st);
             hipLaunchKernelGGL(k_gen_gi, dim3(gridHS), dim3(256), 0, st, dFrame, wb, c0, &wb.counts[64 + c]);
-            rt_stage_end(ctx, ST_GEN_GI, 1);
+            rt_stage_end(ctx, ST_GEN_GI, 1, st);
 
             DualQueueSrc qq;
             qq.a = q1;
             qq.b.o = wb.sh2O; qq.b.d = wb.sh2D; qq.b.tm = wb.sh2T; qq.b.liveCount = &wb.counts[64 + c]; qq.b.c0 = 0; qq.b.cap = wb.CH * (uint32_t)SPP;
             qq.b.stride = wb.CH * (uint32_t)SPP; qq.b.slots = 6u;
             qq.b.outT = nullptr; qq.b.outTri = nullptr; qq.b.outOcc = wb.occ2;
-            rt_stage_begin(ctx, ST_TRACE_SHADOW);
+            rt_stage_begin(ctx, ST_TRACE_SHADOW, st);
             launch_trace<DualQueueSrc, true>(st, traceBlocks, treeDepth, dFrame, host.sc, qq, &wb.heads[(size_t)(1 + c * 3 + 0) * kHeadWords], &wb.counts[3], tune, S ? S + 16 : nullptr);
-            rt_stage_end(ctx, ST_TRACE_SHADOW, 1);
+            rt_stage_end(ctx, ST_TRACE_SHADOW, 1, st);
         } else {
-            rt_stage_begin(ctx, ST_TRACE_SHADOW);
+            rt_stage_begin(ctx, ST_TRACE_SHADOW, st);
             launch_trace<QueueSrc, true>(st, traceBlocks, treeDepth, dFrame, host.sc, q1, &wb.heads[(size_t)(1 + c * 3 + 0) * kHeadWords], &wb.counts[3], tune, S ? S + 16 : nullptr);
-            rt_stage_end(ctx, ST_TRACE_SHADOW, 1);
+            rt_stage_end(ctx, ST_TRACE_SHADOW, 1, st);
         }
-        rt_stage_begin(ctx, ST_COMBINE);
+        rt_stage_begin(ctx, ST_COMBINE, st);
         hipLaunchKernelGGL(k_combine, dim3(gridH), dim3(256), 0, st, dFrame, tg, wb, c0);
-        rt_stage_end(ctx, ST_COMBINE, 1);
+        rt_stage_end(ctx, ST_COMBINE, 1, st);
     }
     hipLaunchKernelGGL(k_accum_tally, dim3(1), dim3(64), 0, st, w->counts, w->acc);
+    // temporal resolve: the one stage that needs the previous frame's COLOR0 (and must not overtake its target stores)
+    if (evPrevDone) W_TRY(hipStreamWaitEvent(st, evPrevDone, 0));
+    rt_stage_begin(ctx, ST_RESOLVE, st);
+    hipLaunchKernelGGL(k_resolve, dim3(tiles), dim3(256), 0, st, dFrame, tg, wb);
+    rt_stage_end(ctx, ST_RESOLVE, 1, st);
     W_TRY(hipGetLastError());
     return RT_OK;
 }

@@ -10,9 +10,10 @@ struct RtWave;
 RtWave *rt_wave_create(int computeUnits);
 void rt_wave_destroy(RtWave *w);
 const char *rt_wave_error(const RtWave *w);
-// Renders one frame of a BVH scene into `tg`.  `host` is the host copy of *dFrame.
+// Renders one frame of a BVH scene into `tg` on `stream`.  `host` is the host copy of *dFrame.  Only the final temporal
+// resolve waits for `evPrevDone` (the previous frame's completion event, may be null).
 int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t stream, const rtd::DevFrame *dFrame, const rtd::DevFrame &host,
-                   rtd::Targets tg, unsigned long long *counters, bool count, int treeDepth);
+                   rtd::Targets tg, unsigned long long *counters, bool count, int treeDepth, hipEvent_t evPrevDone);
 
 // traced-ray tallies accumulated since the last reset: [0] candidate pixels [1] hit pixels [2] primary [3] shadow+AO
 // [4] bounce [5] bounce-shadow rays actually traversed, [6] frames

@@ -32,7 +32,7 @@ class FrameGatherer:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.device = torch.device("cuda", torch.cuda.current_device())
-        self.stream = torch.cuda.ExternalStream(renderer.stream(), device=self.device)
+        self._streams = {}
         self.block = renderer.gather_block_bytes(which)
         ch = TARGET_CHANNELS[which]
         self.gathered = self.frame = None
@@ -51,7 +51,11 @@ class FrameGatherer:
     def gather(self):
         """Enqueue gather + assemble behind the frame just rendered (asynchronous; same stream as the kernels)."""
         loc = self._local()
-        with torch.cuda.stream(self.stream):
+        sp = self.ren.stream()                 # consecutive frames alternate between two streams: follow the last frame's
+        stream = self._streams.get(sp)
+        if stream is None:
+            stream = self._streams[sp] = torch.cuda.ExternalStream(sp, device=self.device)
+        with torch.cuda.stream(stream):
             if self.world > 1:
                 dist.gather(loc, list(self.gathered.unbind(0)) if self.rank == 0 else None, dst=0, group=self.group)
             elif self.rank == 0:

@@ -333,3 +333,42 @@ def test_moving_camera_reprojection(orc, pipeline, use_bvh):
                 assert np.abs(mot).max() > 0       # real motion vectors were produced
             prev, prev_vp = want[0], vp
         assert moved_frames == 3
+
+
+def test_million_triangle_scene_deep_tree(orc):
+    """BASELINE configs[4]'s scene (16 objects, 1 M triangles, tree depth 18): exercises the 24-entry closest-hit and
+    36-entry any-hit LDS stacks and the chunked queues.  Full-frame oracle runs are too slow for a test, so: wavefront ==
+    megakernel bit for bit on a 640x360 frame, plus an oracle window."""
+    v, f = rt.meshgen.million_triangle_scene()
+    tris9 = rt.gather_triangles(v, f, np.eye(4, dtype=np.float32).reshape(-1))
+    nodes, tris = rt.build_bvh(tris9)
+    assert tris.shape[0] == 1_000_000
+    faces = scenes.tiny_env(16)
+    W, H = 640, 360
+    p = rt.default_render_params()
+    p.sppPerFrame = 2
+    cam = scenes.camera("default", aspect=W / H)
+    outs = {}
+    for name, pipe in (("mega", rt.RT_PIPELINE_MEGAKERNEL), ("wave", rt.RT_PIPELINE_WAVEFRONT)):
+        with rt.Renderer(pipeline=pipe) as r:
+            r.upload_bvh(nodes, tris)
+            r.upload_env(faces)
+            r.resize(W, H)
+            for frame in range(2):
+                u = rt.frame_uniforms(p, cam, W, H, frame, True, nodes.shape[0], tris.shape[0])
+                r.render_frame(u)
+            outs[name] = r.read_all()
+    for a, b in zip(outs["mega"], outs["wave"]):
+        assert np.array_equal(a, b)
+    assert outs["wave"][2].any()           # geometry was hit
+    with rt.Renderer() as r:
+        r.upload_bvh(nodes, tris)
+        r.upload_env(faces)
+        r.resize(W, H)
+        u = rt.frame_uniforms(p, cam, W, H, 0, True, nodes.shape[0], tris.shape[0])
+        r.render_frame(u)
+        got = r.read_all()
+    x0, y0, x1, y1 = 300, 100, 340, 120
+    want, _ = orc.render(u, nodes, tris, faces, None, region=(x0, y0, x1, y1))
+    for g, w_ in zip(got, want):
+        assert np.array_equal(g[y0:y1, x0:x1], w_[y0:y1, x0:x1])
