@@ -115,8 +115,10 @@ def main():
         ren = make_renderer(False)
         gatherer = FrameGatherer(ren) if world > 1 else None
 
+        frames_u = [uniforms(cam, f) for f in range(warmup + steps)]   # inputs prepared outside the timed region
+
         def step(f):
-            ren.render_frame(uniforms(cam, f))
+            ren.render_frame(frames_u[f])
             if gatherer:
                 gatherer.gather()      # one RCCL gather of COLOR0 to rank 0 + un-tiling kernel, on the renderer's stream
 

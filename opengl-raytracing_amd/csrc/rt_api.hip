@@ -19,14 +19,19 @@ using namespace rtd;
 
 static thread_local std::string g_createError;
 
+#define RT_MAX_LANES 8
 struct StageEvent { int stage; hipEvent_t a, b; };
 
 struct RtContext {
     RtDeviceConfig cfg{};
-    hipStream_t stream = nullptr;        // lane 0 (even frames) and every non-frame operation
-    hipStream_t stream2 = nullptr;       // lane 1 (odd frames): consecutive frames overlap up to the temporal resolve
+    // Frames in flight: frame f runs on lane f % nLanes (own stream, frame descriptor, ray-queue arenas, COLOR0 buffer), so
+    // up to nLanes consecutive frames overlap everywhere except at the temporal resolve.  stream == lanes[0]: every
+    // non-frame operation runs there after a sync of all lanes.
+    int nLanes = 3;
+    hipStream_t lanes[RT_MAX_LANES] = {};
+    hipStream_t stream = nullptr;
     hipStream_t lastStream = nullptr;    // stream of the most recent frame (gather / assemble are ordered behind it)
-    hipEvent_t evDone[2] = {nullptr, nullptr};   // frame on lane i has written its targets
+    hipEvent_t evDone[RT_MAX_LANES] = {};   // the frame on lane i has written its targets
     std::string err;
     // scene
     float4 *dWNodes = nullptr, *dW4 = nullptr, *dTris = nullptr;
@@ -37,18 +42,18 @@ struct RtContext {
     // frame state
     FrameGeom g{};
     bool sized = false;
-    uint2 *dColor[2] = {nullptr, nullptr};
+    uint2 *dColor[RT_MAX_LANES] = {};   // COLOR0 ring: frame f writes [f % nLanes], reads [(f-1) % nLanes]
     uint32_t *dMotion = nullptr;
     uint2 *dGPos = nullptr, *dGNrm = nullptr;
     size_t nSlots = 0;
     int frameIndex = 0, writeIdx = 0;     // include/render/accum.h:125-138
     bool haveFrameState = false;
     float prevVP[16];
-    DevFrame *dFrame[2] = {nullptr, nullptr};
+    DevFrame *dFrame[RT_MAX_LANES] = {};
     unsigned long long *dCounters = nullptr;
     void *dStaging = nullptr;
     size_t stagingBytes = 0;
-    RtWave *wave[2] = {nullptr, nullptr};
+    RtWave *wave[RT_MAX_LANES] = {};
     // timing
     bool timing = false;
     std::vector<StageEvent> pending;
@@ -68,9 +73,10 @@ static int fail(RtContext *c, int code, const char *fmt, ...) {
     return code;
 }
 static hipError_t sync_all(RtContext *c) {
-    hipError_t e = hipStreamSynchronize(c->stream);
-    hipError_t e2 = c->stream2 ? hipStreamSynchronize(c->stream2) : hipSuccess;
-    return e != hipSuccess ? e : e2;
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < c->nLanes; ++i)
+        if (c->lanes[i]) { hipError_t ei = hipStreamSynchronize(c->lanes[i]); if (e == hipSuccess) e = ei; }
+    return e;
 }
 #define HIP_TRY(c, expr)                                                                                  \
     do {                                                                                                  \
@@ -178,7 +184,7 @@ DevScene make_dev_scene(const RtContext *c) {
 }
 
 void free_targets(RtContext *c) {
-    for (int i = 0; i < 2; ++i) { if (c->dColor[i]) (void)hipFree(c->dColor[i]); c->dColor[i] = nullptr; }
+    for (int i = 0; i < RT_MAX_LANES; ++i) { if (c->dColor[i]) (void)hipFree(c->dColor[i]); c->dColor[i] = nullptr; }
     if (c->dMotion) (void)hipFree(c->dMotion);
     if (c->dGPos) (void)hipFree(c->dGPos);
     if (c->dGNrm) (void)hipFree(c->dGNrm);
@@ -197,7 +203,7 @@ int ensure_staging(RtContext *c, size_t bytes) {
 
 void *target_ptr(RtContext *c, int which, int &channels) {
     switch (which) {
-        case RT_TARGET_COLOR: channels = 4; return c->dColor[1 - c->writeIdx];   // last frame written = current read ping
+        case RT_TARGET_COLOR: channels = 4; return c->dColor[(c->writeIdx + c->nLanes - 1) % c->nLanes];   // the frame written last
         case RT_TARGET_MOTION: channels = 2; return c->dMotion;
         case RT_TARGET_GPOS: channels = 4; return c->dGPos;
         case RT_TARGET_GNRM: channels = 4; return c->dGNrm;
@@ -258,16 +264,21 @@ int rt_create(const RtDeviceConfig *cfg, RtContext **out) {
         return fail(nullptr, RT_ERR_UNSUPPORTED, "rt_create: device is %s, this library carries gfx950 code only", prop.gcnArchName);
     RtContext *c = new RtContext();
     c->cfg = *cfg;
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
-        hipMalloc(&c->dFrame[0], sizeof(DevFrame)) != hipSuccess || hipMalloc(&c->dFrame[1], sizeof(DevFrame)) != hipSuccess ||
-        hipEventCreateWithFlags(&c->evDone[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->evDone[1], hipEventDisableTiming) != hipSuccess ||
-        hipMalloc(&c->dCounters, 8 * sizeof(unsigned long long)) != hipSuccess) {
-        delete c;
+    // measured on MI355X (1080p / 4 spp): whole frame on one GPU 3.0 / 2.48 / 2.44 / 2.58 ms with 1 / 2 / 3 / 4 lanes; one rank of
+    // eight (1/8 of the tiles, latency-bound stages) 0.92 / 0.64 / 0.56 / 0.51 ms
+    c->nLanes = cfg->worldSize > 1 ? 4 : 3;
+    if (const char *e = getenv("RT_LANES")) c->nLanes = std::max(1, std::min(RT_MAX_LANES, atoi(e)));
+    bool ok = hipMalloc(&c->dCounters, 8 * sizeof(unsigned long long)) == hipSuccess;
+    for (int i = 0; ok && i < c->nLanes; ++i)
+        ok = hipStreamCreateWithFlags(&c->lanes[i], hipStreamNonBlocking) == hipSuccess && hipMalloc(&c->dFrame[i], sizeof(DevFrame)) == hipSuccess &&
+             hipEventCreateWithFlags(&c->evDone[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        rt_destroy(c);
         return fail(nullptr, RT_ERR_HIP, "rt_create: stream/alloc failed");
     }
+    c->stream = c->lanes[0];
     (void)hipMemset(c->dCounters, 0, 8 * sizeof(unsigned long long));
-    c->wave[0] = rt_wave_create(prop.multiProcessorCount);
-    c->wave[1] = rt_wave_create(prop.multiProcessorCount);
+    for (int i = 0; i < c->nLanes; ++i) c->wave[i] = rt_wave_create(prop.multiProcessorCount);
     c->lastStream = c->stream;
     int rc = rt_upload_env(c, nullptr, 0, 0);   // dummy cube map like Application::initState (application.cpp:281)
     if (rc != RT_OK) { g_createError = c->err; rt_destroy(c); return rc; }
@@ -278,10 +289,10 @@ int rt_create(const RtDeviceConfig *cfg, RtContext **out) {
 void rt_destroy(RtContext *c) {
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
-    if (c->stream) (void)sync_all(c);
+    (void)sync_all(c);
     free_targets(c);
-    for (int i = 0; i < 2; ++i) { if (c->wave[i]) rt_wave_destroy(c->wave[i]); if (c->dFrame[i]) (void)hipFree(c->dFrame[i]); if (c->evDone[i]) (void)hipEventDestroy(c->evDone[i]); }
-    if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    for (int i = 0; i < RT_MAX_LANES; ++i) { if (c->wave[i]) rt_wave_destroy(c->wave[i]); if (c->dFrame[i]) (void)hipFree(c->dFrame[i]); if (c->evDone[i]) (void)hipEventDestroy(c->evDone[i]); }
+    for (int i = 1; i < RT_MAX_LANES; ++i) if (c->lanes[i]) (void)hipStreamDestroy(c->lanes[i]);
     if (c->dWNodes) (void)hipFree(c->dWNodes);
     if (c->dW4) (void)hipFree(c->dW4);
     if (c->dTris) (void)hipFree(c->dTris);
@@ -457,7 +468,7 @@ int rt_resize(RtContext *c, int w, int h) {
     // every rank allocates the padded size so gather blocks are equal
     const size_t maxLocal = (size_t)(g.nTiles + g.world - 1) / g.world;
     c->nSlots = std::max<size_t>(maxLocal, 1) * RT_TILE_PIXELS;
-    for (int i = 0; i < 2; ++i) HIP_TRY(c, hipMalloc(&c->dColor[i], c->nSlots * 8));
+    for (int i = 0; i < c->nLanes; ++i) HIP_TRY(c, hipMalloc(&c->dColor[i], c->nSlots * 8));
     HIP_TRY(c, hipMalloc(&c->dMotion, c->nSlots * 4));
     HIP_TRY(c, hipMalloc(&c->dGPos, c->nSlots * 8));
     HIP_TRY(c, hipMalloc(&c->dGNrm, c->nSlots * 8));
@@ -473,7 +484,7 @@ int rt_reset_accum(RtContext *c) {
     HIP_TRY(c, sync_all(c));
     c->frameIndex = 0;
     c->writeIdx = 0;
-    for (int i = 0; i < 2; ++i) HIP_TRY(c, hipMemsetAsync(c->dColor[i], 0, c->nSlots * 8, c->stream));
+    for (int i = 0; i < c->nLanes; ++i) HIP_TRY(c, hipMemsetAsync(c->dColor[i], 0, c->nSlots * 8, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->dMotion, 0, c->nSlots * 4, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->dGPos, 0, c->nSlots * 8, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->dGNrm, 0, c->nSlots * 8, c->stream));
@@ -499,25 +510,25 @@ int rt_render_frame(RtContext *c, const RtUniforms *uIn) {
     fr.sc = make_dev_scene(c);
     if (!(fr.u.nodeCount > 0 && fr.u.triCount > 0)) fr.sc.hasBVH = 0;
     fr.g = c->g;
-    // Lane = parity of the frame index = index of the COLOR0 buffer this frame writes: consecutive frames alternate between
-    // two streams and overlap everywhere except at the temporal resolve (the only read of the previous frame), and every
-    // later reader of a COLOR0 buffer (gather, assemble) is stream-ordered before the next writer of the same buffer.
-    const int lane = c->writeIdx;
-    hipStream_t st = lane ? c->stream2 : c->stream;
+    // Lane = frame index mod nLanes = index of the COLOR0 buffer this frame writes: consecutive frames rotate over the lanes'
+    // streams and overlap everywhere except at the temporal resolve (the only read of the previous frame), and every later
+    // reader of a COLOR0 buffer (gather, assemble) is stream-ordered before the next writer of the same buffer.
+    const int lane = c->writeIdx, prevLane = (c->writeIdx + c->nLanes - 1) % c->nLanes;
+    hipStream_t st = c->lanes[lane];
     HIP_TRY(c, hipMemcpyAsync(c->dFrame[lane], &fr, sizeof(fr), hipMemcpyHostToDevice, st));
     Targets tg;
     tg.color = c->dColor[c->writeIdx];
-    tg.prev = c->dColor[1 - c->writeIdx];
+    tg.prev = c->dColor[prevLane];
     tg.motion = c->dMotion; tg.gpos = c->dGPos; tg.gnrm = c->dGNrm;
     const bool count = c->cfg.countWork != 0;
     int pipeline = c->cfg.pipeline;
     if (pipeline == RT_PIPELINE_AUTO) pipeline = (fr.u.useBVH == 1 && fr.sc.hasBVH && !count) ? RT_PIPELINE_WAVEFRONT : RT_PIPELINE_MEGAKERNEL;
     if (pipeline == RT_PIPELINE_WAVEFRONT && !(fr.u.useBVH == 1)) pipeline = RT_PIPELINE_MEGAKERNEL;   // analytic scene: pure ALU, megakernel only
     if (pipeline == RT_PIPELINE_WAVEFRONT) {
-        int rc = rt_wave_render(c->wave[lane], c, st, c->dFrame[lane], fr, tg, c->dCounters, count, std::max(c->treeDepth, 1), c->evDone[1 - lane]);
+        int rc = rt_wave_render(c->wave[lane], c, st, c->dFrame[lane], fr, tg, c->dCounters, count, std::max(c->treeDepth, 1), c->nLanes > 1 ? c->evDone[prevLane] : nullptr);
         if (rc != RT_OK) return fail(c, rc, "wavefront pipeline: %s", rt_wave_error(c->wave[lane]));
     } else {
-        HIP_TRY(c, hipStreamWaitEvent(st, c->evDone[1 - lane], 0));   // the megakernel reads the history from its first instruction on
+        if (c->nLanes > 1) HIP_TRY(c, hipStreamWaitEvent(st, c->evDone[prevLane], 0));   // the megakernel reads the history from its first instruction on
         rt_stage_begin(c, 0, st);
         HIP_TRY(c, rtl::launch_mega(st, c->dFrame[lane], tg, c->dCounters, count, std::max(c->treeDepth, 1), c->g.nLocalTiles));
         rt_stage_end(c, 0, 1, st);
@@ -526,7 +537,7 @@ int rt_render_frame(RtContext *c, const RtUniforms *uIn) {
     c->lastStream = st;
     if (c->timing) c->timedFrames++;
     c->frameIndex++;                 // Accum::swapAfterFrame, include/render/accum.h:125-128
-    c->writeIdx = 1 - c->writeIdx;
+    c->writeIdx = (c->writeIdx + 1) % c->nLanes;
     return RT_OK;
 }
 
@@ -585,7 +596,7 @@ int rt_present(RtContext *c, const RtPresentParams *p, uint8_t *dst) {
     int rc = ensure_staging(c, bytes);
     if (rc != RT_OK) return rc;
     rt_stage_begin(c, 11);
-    HIP_TRY(c, rtl::launch_present(c->stream, c->g, c->dColor[1 - c->writeIdx], c->dMotion, c->dGPos, c->dGNrm, *p, (uint32_t *)c->dStaging));
+    HIP_TRY(c, rtl::launch_present(c->stream, c->g, c->dColor[(c->writeIdx + c->nLanes - 1) % c->nLanes], c->dMotion, c->dGPos, c->dGNrm, *p, (uint32_t *)c->dStaging));
     rt_stage_end(c, 11, 1);
     HIP_TRY(c, hipMemcpyAsync(dst, c->dStaging, bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, sync_all(c));
@@ -650,9 +661,9 @@ int rt_get_traced_rays(RtContext *c, RtTracedRays *out, int reset) {
     (void)hipSetDevice(c->cfg.device);
     unsigned long long v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     (void)sync_all(c);
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < c->nLanes; ++i) {
         unsigned long long t[8];
-        int rc = rt_wave_traced(c->wave[i], i ? c->stream2 : c->stream, t, reset != 0);
+        int rc = rt_wave_traced(c->wave[i], c->lanes[i], t, reset != 0);
         if (rc != RT_OK) return fail(c, rc, "rt_get_traced_rays: %s", rt_wave_error(c->wave[i]));
         for (int k = 0; k < 8; ++k) v[k] += t[k];
     }
