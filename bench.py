@@ -161,6 +161,7 @@ def main():
     # wall span; this untimed pass shows what each stage costs when it has the GPU to itself
     serial_stages = None
     if world == 1:
+        old_lanes = os.environ.get("RT_LANES")
         os.environ["RT_LANES"] = "1"
         try:
             r1 = make_renderer(False)
@@ -174,7 +175,10 @@ def main():
             serial_stages = {k: v["ms"] / 8 for k, v in sst["stages"].items()}
             r1.close()
         finally:
-            del os.environ["RT_LANES"]
+            if old_lanes is None:
+                del os.environ["RT_LANES"]
+            else:
+                os.environ["RT_LANES"] = old_lanes
     res = closeup
     rays = res["counters"].rays
     mray = rays / res["seconds"] / 1e6
@@ -187,34 +191,47 @@ def main():
         name, dom = max(st["stages"].items(), key=lambda kv: kv[1]["ms"])
         launches = max(int(dom["launches"]), 1)
         avg_ms = dom["ms"] / launches
+        overlapped_span_ms = None
+        if serial_stages and name in serial_stages:
+            # With several frames in flight the event span of a stage includes time its kernel shares the GPU with (or queues
+            # behind) other frames' kernels; the one-frame-in-flight pass gives the kernel's own duration, which is what
+            # rocprofv3's kernel trace reports (profiles/r01_wavefront_kernel_stats*.csv).
+            overlapped_span_ms = avg_ms
+            avg_ms = serial_stages[name] * args.steps / launches
         lc = res["local_counters"]
-        # algorithmic bytes of this rank's share of one frame, all attributed to the pipeline's kernels;
-        # with one kernel per frame (megakernel) that is exactly the kernel's bytes per launch.
+        # algorithmic bytes (reference layout, SURVEY 8d: 48 B per nodeFetch / triFetch) of the rays this kernel traverses,
+        # from the per-ray-kind fetch counters of the counting pass; non-traversal stages and the megakernel get the
+        # frame's bytes split by device-time share.
+        fetch_rest = lc.nodeFetch + lc.triFetch - lc.fetchPrimary - lc.fetchShadow - lc.fetchAO
+        per_kind = {"trace_primary": lc.fetchPrimary, "trace_shadow": lc.fetchShadow + lc.fetchAO, "trace_gi": fetch_rest}
         bytes_per_frame = algorithmic_bytes(lc, npix // world) / args.steps
-        share = dom["ms"] / max(sum(v["ms"] for v in st["stages"].values()), 1e-9)
-        bytes_per_launch = bytes_per_frame * (1.0 if len(st["stages"]) == 1 else share) * args.steps / launches
+        if name in per_kind:
+            bytes_per_launch = 48.0 * per_kind[name] / launches
+            attribution = ("48 B x (nodeFetch + triFetch) of the reference's traversal for the rays this kernel traces "
+                           "(trace_shadow: traceBVHShadow rays + computeAO rays), megakernel counting pass")
+        else:
+            share = dom["ms"] / max(sum(v["ms"] for v in st["stages"].values()), 1e-9)   # same overlap factor on both sides
+            bytes_per_launch = bytes_per_frame * (1.0 if len(st["stages"]) == 1 else share) * args.steps / launches
+            attribution = "frame's reference-layout bytes x this kernel's share of the frame's device time"
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
         # HBM bytes of that kernel per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
         # passes, gfx950 2x fetch correction; profiles/README.md).  PMC cannot be collected from inside the timed run.
         traffic, traffic_src = None, None
         tj = ROOT / "profiles" / "r01_wavefront_traffic.json"
-        kmap = {"trace_shadow": "QueueSrc, true", "trace_gi_shadow": "QueueSrc, true", "trace_gi": "QueueSrc, false",
+        kmap = {"trace_shadow": "DualQueueSrc, true", "trace_gi": "QueueSrc, false",
                 "trace_primary": "PrimarySrc", "primary": "k_primary", "combine": "k_combine", "gen_direct": "k_gen_direct"}
         if world == 1 and tj.exists() and name in kmap:
             for k, v in json.load(open(tj))["kernels"].items():
                 if kmap[name] in k:
                     per_frame = v["hbm_bytes_per_frame_corrected"]
-                    # the any-hit kernel runs twice per frame (shadow + bounce-shadow); split by time share
-                    if "QueueSrc, true" in k:
-                        both = st["stages"].get("trace_shadow", {"ms": 0})["ms"] + st["stages"].get("trace_gi_shadow", {"ms": 0})["ms"]
-                        per_frame *= dom["ms"] / max(both, 1e-9)
                     traffic = per_frame * args.steps / launches
                     traffic_src = "profiles/r01_wavefront_traffic.json"
         roofline = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                     "avg_launch_ms": avg_ms, "launches": launches, "algorithmic_bytes_per_launch": bytes_per_launch,
-                    "attribution": "frame's reference-layout bytes (48 B/nodeFetch, 48 B/triFetch, 12 B/env lookup, 36 B/pixel; megakernel "
-                                   "counters) x this kernel's share of the frame's device time",
+                    "attribution": attribution,
+                    "avg_launch_ms_source": "HIP events, one frame in flight" if overlapped_span_ms is not None else "HIP events, timed region",
+                    "event_span_ms_with_frames_overlapping": overlapped_span_ms,
                     "note": "BVH (1 MB nodes + 3.9 MB tris) is L2/Infinity-Cache resident and the reference layout fetches 3x48 B per node visit, "
                             "so algorithmic bytes/s exceed the HBM peak (frac > 1) while measured HBM traffic is ~7% of peak: the kernel is bound by "
                             "vector-cache gather rate/latency, see DESIGN.md 4.3 and profiles/README.md"}

@@ -99,6 +99,9 @@ typedef struct RtCamera { float pos[3], yaw, pitch, fov, aspect; } RtCamera;
  * shaders/rt/rt_bvh.glsl (48 B each in the reference layout). */
 typedef struct RtCounters {
     uint64_t raysClosest, raysShadow, raysAnalytic, nodeFetch, triFetch, envLookup, hitPixels;
+    /* nodeFetch + triFetch split by the kind of ray: primary rays (rt.frag:86), traceBVHShadow rays, computeAO's rays
+     * (rt_lighting.glsl:721-757); what is left belongs to the bounce's closest-hit rays. */
+    uint64_t fetchPrimary, fetchShadow, fetchAO;
 } RtCounters;
 
 typedef enum RtPipeline {

@@ -106,7 +106,8 @@ class RtCamera(_Struct):
 
 
 class RtCounters(_Struct):
-    _fields_ = [(n, C.c_uint64) for n in ("raysClosest", "raysShadow", "raysAnalytic", "nodeFetch", "triFetch", "envLookup", "hitPixels")]
+    _fields_ = [(n, C.c_uint64) for n in ("raysClosest", "raysShadow", "raysAnalytic", "nodeFetch", "triFetch", "envLookup", "hitPixels",
+                                             "fetchPrimary", "fetchShadow", "fetchAO")]
 
     @property
     def rays(self):

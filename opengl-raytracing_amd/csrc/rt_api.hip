@@ -268,7 +268,7 @@ int rt_create(const RtDeviceConfig *cfg, RtContext **out) {
     // eight (1/8 of the tiles, latency-bound stages) 0.92 / 0.64 / 0.56 / 0.51 ms
     c->nLanes = cfg->worldSize > 1 ? 4 : 3;
     if (const char *e = getenv("RT_LANES")) c->nLanes = std::max(1, std::min(RT_MAX_LANES, atoi(e)));
-    bool ok = hipMalloc(&c->dCounters, 8 * sizeof(unsigned long long)) == hipSuccess;
+    bool ok = hipMalloc(&c->dCounters, 16 * sizeof(unsigned long long)) == hipSuccess;
     for (int i = 0; ok && i < c->nLanes; ++i)
         ok = hipStreamCreateWithFlags(&c->lanes[i], hipStreamNonBlocking) == hipSuccess && hipMalloc(&c->dFrame[i], sizeof(DevFrame)) == hipSuccess &&
              hipEventCreateWithFlags(&c->evDone[i], hipEventDisableTiming) == hipSuccess;
@@ -277,7 +277,7 @@ int rt_create(const RtDeviceConfig *cfg, RtContext **out) {
         return fail(nullptr, RT_ERR_HIP, "rt_create: stream/alloc failed");
     }
     c->stream = c->lanes[0];
-    (void)hipMemset(c->dCounters, 0, 8 * sizeof(unsigned long long));
+    (void)hipMemset(c->dCounters, 0, 16 * sizeof(unsigned long long));
     for (int i = 0; i < c->nLanes; ++i) c->wave[i] = rt_wave_create(prop.multiProcessorCount);
     c->lastStream = c->stream;
     int rc = rt_upload_env(c, nullptr, 0, 0);   // dummy cube map like Application::initState (application.cpp:281)
@@ -642,17 +642,18 @@ int rt_get_counters(RtContext *c, RtCounters *out) {
     if (!c || !out) return RT_ERR_INVALID;
     if (!c->cfg.countWork) return fail(c, RT_ERR_STATE, "rt_get_counters: context created without countWork");
     (void)hipSetDevice(c->cfg.device);
-    unsigned long long v[8];
+    unsigned long long v[16];
     HIP_TRY(c, sync_all(c));
     HIP_TRY(c, hipMemcpy(v, c->dCounters, sizeof v, hipMemcpyDeviceToHost));
     out->raysClosest = v[0]; out->raysShadow = v[1]; out->raysAnalytic = v[2]; out->nodeFetch = v[3];
     out->triFetch = v[4]; out->envLookup = v[5]; out->hitPixels = v[6];
+    out->fetchPrimary = v[7]; out->fetchShadow = v[8]; out->fetchAO = v[9];
     return RT_OK;
 }
 int rt_reset_counters(RtContext *c) {
     if (!c) return RT_ERR_INVALID;
     (void)hipSetDevice(c->cfg.device);
-    HIP_TRY(c, hipMemsetAsync(c->dCounters, 0, 8 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->dCounters, 0, 16 * sizeof(unsigned long long), c->stream));
     return RT_OK;
 }
 

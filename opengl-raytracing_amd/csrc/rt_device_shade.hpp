@@ -39,8 +39,13 @@ struct DevScene {
 
 struct Work {   // RtCounters, per lane
     uint32_t raysClosest, raysShadow, raysAnalytic, nodeFetch, triFetch, envLookup, hitPixels;
+    uint32_t fetchPrimary, fetchShadow, fetchAO;
+    RT_DEV uint32_t fetches() const { return nodeFetch + triFetch; }
 };
-RT_DEV void work_zero(Work &w) { w.raysClosest = w.raysShadow = w.raysAnalytic = w.nodeFetch = w.triFetch = w.envLookup = w.hitPixels = 0; }
+RT_DEV void work_zero(Work &w) {
+    w.raysClosest = w.raysShadow = w.raysAnalytic = w.nodeFetch = w.triFetch = w.envLookup = w.hitPixels = 0;
+    w.fetchPrimary = w.fetchShadow = w.fetchAO = 0;
+}
 
 struct Hit { float t; V3 p; V3 n; int mat; };   // rt_common.glsl:39-44
 

@@ -79,10 +79,11 @@ struct HistoryTex {
     }
 };
 
-// Block-wide accumulation of per-lane work counters into the 7 global 64-bit counters.
+// Block-wide accumulation of per-lane work counters into the 10 global 64-bit counters.
 RT_DEV void flush_work(const Work &w, unsigned long long *counters) {
-    const uint32_t v[7] = {w.raysClosest, w.raysShadow, w.raysAnalytic, w.nodeFetch, w.triFetch, w.envLookup, w.hitPixels};
-    for (int i = 0; i < 7; ++i) {
+    const uint32_t v[10] = {w.raysClosest, w.raysShadow, w.raysAnalytic, w.nodeFetch, w.triFetch, w.envLookup, w.hitPixels,
+                            w.fetchPrimary, w.fetchShadow, w.fetchAO};
+    for (int i = 0; i < 10; ++i) {
         unsigned long long s = v[i];
         for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
         if ((threadIdx.x & 63) == 0 && s) atomicAdd(&counters[i], s);

@@ -20,7 +20,12 @@ struct InlineTracer {
     StackEntry *stk;
     Work *w;
     // the megakernel is the reference-shaped baseline: it traces every ray the reference casts, needed or not
-    __device__ __noinline__ bool shadow(int, int, V3 ro, V3 rd, float tMax, bool) { return bvh_anyhit<COUNT>(*sc, ro, rd, eps, tMax, stk, *w); }
+    __device__ __noinline__ bool shadow(int, int, V3 ro, V3 rd, float tMax, bool) {
+        uint32_t f0 = w->fetches();
+        bool r = bvh_anyhit<COUNT>(*sc, ro, rd, eps, tMax, stk, *w);
+        if (COUNT) w->fetchShadow += w->fetches() - f0;
+        return r;
+    }
     __device__ __noinline__ bool closest(V3 ro, V3 rd, float &t, int &tri) { return bvh_closest<COUNT>(*sc, ro, rd, eps, inf, stk, t, tri, *w); }
     RT_DEV int gi(V3 ro, V3 rd, V3 &hp, V3 &hn) {
         float t;
@@ -75,6 +80,7 @@ __global__ __launch_bounds__(256) void k_mega(const DevFrame *__restrict__ fr, T
                 w.raysClosest += (w.raysClosest - w0.raysClosest) * (uint32_t)(SPP - 1);
                 w.nodeFetch += (w.nodeFetch - w0.nodeFetch) * (uint32_t)(SPP - 1);
                 w.triFetch += (w.triFetch - w0.triFetch) * (uint32_t)(SPP - 1);
+                w.fetchPrimary += w.fetches() - w0.fetches();
             }
             if (hitAny) {
                 const V3 hp = camPos + dir * tHit;
@@ -93,6 +99,7 @@ __global__ __launch_bounds__(256) void k_mega(const DevFrame *__restrict__ fr, T
                         w.raysClosest += (w.raysClosest - w1.raysClosest) * (uint32_t)(SPP - 1);
                         w.nodeFetch += (w.nodeFetch - w1.nodeFetch) * (uint32_t)(SPP - 1);
                         w.triFetch += (w.triFetch - w1.triFetch) * (uint32_t)(SPP - 1);
+                        w.fetchAO += w.fetches() - w1.fetches();
                     }
                 }
                 for (int s = 0; s < SPP; ++s) {

@@ -78,6 +78,9 @@ typedef struct OrcCounters {
     uint64_t triFetch;        // triFetch() calls, 48 B each (rt_bvh.glsl:55)
     uint64_t envLookup;       // texture(uEnvMap, .) calls
     uint64_t hitPixels;       // pixels whose primary ray hit (s == 0)
+    uint64_t fetchPrimary;    // node+tri fetches made by the primary rays (rt.frag:86)
+    uint64_t fetchShadow;     //   ... by traceBVHShadow (direct and bounce shadow rays)
+    uint64_t fetchAO;         //   ... by computeAO's closest-hit rays (rt_lighting.glsl:721-757); the rest: the bounce rays
 } OrcCounters;
 
 #ifdef __cplusplus

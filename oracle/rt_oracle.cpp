@@ -24,6 +24,9 @@ namespace orc {
 struct Counters {
     uint64_t raysClosest = 0, raysShadow = 0, raysAnalytic = 0, nodeFetch = 0, triFetch = 0, envLookup = 0,
              hitPixels = 0;
+    // node+tri fetches split by the kind of ray that made them (the rest are the bounce's closest-hit rays)
+    uint64_t fetchPrimary = 0, fetchShadow = 0, fetchAO = 0;
+    uint64_t fetches() const { return nodeFetch + triFetch; }
 };
 
 // Everything a fragment invocation can see: uniforms + bound resources.
@@ -298,7 +301,14 @@ static bool traceBVH(const Scene &S, Counters &C, vec3 ro, vec3 rd, Hit &hitOut)
     }
     return hitOut.t < S.u.inf;
 }
-static bool traceBVHShadow(const Scene &S, Counters &C, vec3 ro, vec3 rd, float tMax) {   // :260-304
+static bool traceBVHShadowImpl(const Scene &S, Counters &C, vec3 ro, vec3 rd, float tMax);
+static bool traceBVHShadow(const Scene &S, Counters &C, vec3 ro, vec3 rd, float tMax) {
+    uint64_t f0 = C.fetches();
+    bool r = traceBVHShadowImpl(S, C, ro, rd, tMax);
+    C.fetchShadow += C.fetches() - f0;
+    return r;
+}
+static bool traceBVHShadowImpl(const Scene &S, Counters &C, vec3 ro, vec3 rd, float tMax) {   // :260-304
     C.raysShadow++;
     if (S.u.nodeCount <= 0 || S.u.triCount <= 0) return false;
     float tminBox, tmaxBox;
@@ -611,7 +621,9 @@ static float computeAO(const Scene &S, Counters &C, const Frag &F, const Hit &h,
         vec3 dir = sampleHemisphereCosine(S, N, u);
         vec3 org = h.p + N * S.u.aoBias;
         Hit tmp;
+        uint64_t f0 = C.fetches();
         bool hitAny = (S.u.useBVH == 1) ? traceBVH(S, C, org, dir, tmp) : traceAnalytic(S, C, org, dir, tmp);
+        C.fetchAO += C.fetches() - f0;
         if (hitAny && tmp.t < S.u.aoRadius) occludedCount++;
     }
     float occ = (float)occludedCount / (float)S.u.aoSamples;
@@ -692,7 +704,9 @@ static PixelOut shadePixel(const Scene &S, Counters &C, int px, int py) {     //
     for (int s = 0; s < SPP; ++s) {
         int seed = (int)((uint32_t)u.frameIndex * (uint32_t)SPP + (uint32_t)s);
         Hit h;
+        uint64_t f0 = C.fetches();
         bool hitAny = (u.useBVH == 1) ? traceBVH(S, C, camPos, dir, h) : traceAnalytic(S, C, camPos, dir, h);
+        C.fetchPrimary += C.fetches() - f0;
         vec3 radiance;
         if (hitAny) {
             if (s == 0) {
@@ -827,6 +841,7 @@ int orc_render(const OrcUniforms *u, const float *nodes12, const float *tris12, 
         for (auto &C : perThread) {
             c.raysClosest += C.raysClosest; c.raysShadow += C.raysShadow; c.raysAnalytic += C.raysAnalytic;
             c.nodeFetch += C.nodeFetch; c.triFetch += C.triFetch; c.envLookup += C.envLookup; c.hitPixels += C.hitPixels;
+            c.fetchPrimary += C.fetchPrimary; c.fetchShadow += C.fetchShadow; c.fetchAO += C.fetchAO;
         }
         *counters = c;
     }

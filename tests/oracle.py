@@ -22,7 +22,8 @@ _lib = None
 
 
 class OrcCounters(C.Structure):
-    _fields_ = [(n, C.c_uint64) for n in ("raysClosest", "raysShadow", "raysAnalytic", "nodeFetch", "triFetch", "envLookup", "hitPixels")]
+    _fields_ = [(n, C.c_uint64) for n in ("raysClosest", "raysShadow", "raysAnalytic", "nodeFetch", "triFetch", "envLookup", "hitPixels",
+                                             "fetchPrimary", "fetchShadow", "fetchAO")]
 
     @property
     def rays(self):

@@ -35,7 +35,7 @@ def test_pod_layouts():
     L = rt.lib()
     assert L.rt_sizeof_uniforms() == C.sizeof(rt.RtUniforms) == 472
     assert L.rt_sizeof_render_params() == C.sizeof(rt.RtRenderParams)
-    assert C.sizeof(rt.RtCounters) == 56 and C.sizeof(rt.RtDeviceConfig) == 32
+    assert C.sizeof(rt.RtCounters) == 80 and C.sizeof(rt.RtDeviceConfig) == 32
     assert b"gfx950" in L.rt_version()
     assert [L.rt_stage_name(i) for i in range(11)][:3] == [b"mega", b"primary", b"trace_primary"]
 

@@ -237,6 +237,7 @@ def test_bvh_scene_frames(ren, orc, cam_kind, spp):
         c = ren.counters()
         assert (c.raysClosest, c.raysShadow, c.nodeFetch, c.triFetch, c.envLookup, c.hitPixels) == \
                (cnt.raysClosest, cnt.raysShadow, cnt.nodeFetch, cnt.triFetch, cnt.envLookup, cnt.hitPixels)
+        assert (c.fetchPrimary, c.fetchShadow, c.fetchAO) == (cnt.fetchPrimary, cnt.fetchShadow, cnt.fetchAO)
         if cam_kind == "closeup":
             assert cnt.hitPixels > W * H // 5
         prev = want[0]

@@ -226,7 +226,9 @@ def test_golden_fixtures(orc, name):
         outs, cnt = orc.render(u, nodes, tris, env, prev)
         for k, a in zip(("color", "motion", "gpos", "gnrm"), outs):
             assert np.array_equal(a, d[f"{k}{f}"]), (name, f, k)
-        assert tuple(int(v) for v in d["counters"][f]) == cnt.as_tuple()
+        gold = tuple(int(v) for v in d["counters"][f])   # fixtures hold the 7 base counters
+        assert gold == cnt.as_tuple()[:len(gold)]
+        assert cnt.fetchPrimary + cnt.fetchShadow + cnt.fetchAO <= cnt.nodeFetch + cnt.triFetch
         prev = outs[0]
 
 

@@ -8,6 +8,11 @@ cd /tmp && export TMPDIR=/tmp
 # 1. kernel trace + stats of the bench command itself
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --cpu-seconds 0 > $OUT/bench_under_rocprof.log 2>&1
 cp $OUT/trace/*/*kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
+# 1b. the same with one frame in flight (RT_LANES=1): per-kernel durations without cross-frame overlap
+export RT_LANES=1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace1 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --cpu-seconds 0 --no-default-camera > $OUT/bench_under_rocprof_lanes1.log 2>&1
+cp $OUT/trace1/*/*kernel_stats.csv $OUT/kernel_stats_lanes1.csv 2>/dev/null
+unset RT_LANES
 # 2. PMC passes (counters only), separate passes per counter group, on 4 frames of the same workload
 for i in 1 2 3 5 6; do
   case $i in
