@@ -174,6 +174,13 @@ int rt_synchronize(RtContext *ctx);
  * widening).  With worldSize > 1 only this rank's tiles are filled, the rest is zero. */
 int rt_read_target(RtContext *ctx, int which, void *dst, int dstFormat);
 
+/* Inverse of rt_read_target for RT_FORMAT_F16: overwrite one render target "of the last frame" from a full
+ * width x height host image (row 0 = bottom); a rank takes its own tiles.  Writing RT_TARGET_COLOR replaces the
+ * accumulation history the next frame reads (uPrevAccum) -- what glTexSubImage2D on Accum::readTex() would do in
+ * the reference (src/render/accum.cpp:8-20) -- so an accumulation can be restored from a saved frame or a test can
+ * hand the renderer a known history.  The frame index is not touched (see rt_render_frame: it comes from RtUniforms). */
+int rt_write_target(RtContext *ctx, int which, const void *src, int srcFormat);
+
 /* Present pass of renderRay (src/render/render.cpp:199-239 = shaders/rt/rt_present.frag): SVGF-lite 7x7 filter,
  * ACES, gamma 1/2.2 (or the motion visualisation) over the four targets of the last frame -> RGBA8, width*height*4
  * bytes, row 0 = bottom.  RtPresentParams = the uniforms of rt_present.frag:38-50; rt_make_present_params fills

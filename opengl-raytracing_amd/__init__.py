@@ -160,6 +160,7 @@ SIGNATURES = {
     "rt_render_ray": (C.c_int, [C.c_void_p, C.POINTER(RtRenderParams), C.POINTER(RtCamera), C.c_int, C.c_int, _FP, _FP]),
     "rt_synchronize": (C.c_int, [C.c_void_p]),
     "rt_read_target": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
+    "rt_write_target": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "rt_make_present_params": (None, [C.POINTER(RtRenderParams), C.c_int, C.c_int, C.c_int, C.POINTER(RtPresentParams)]),
     "rt_present": (C.c_int, [C.c_void_p, C.POINTER(RtPresentParams), _U8P]),
     "rt_local_target": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
@@ -442,9 +443,22 @@ class Renderer:
         self._check(lib().rt_read_target(self._h, which, out.ctypes.data_as(C.c_void_p), fmt))
         return out
 
+    def write_target(self, which, image) -> None:
+        """Overwrite a target of the last frame from an [H, W, channels] uint16 (half bits) image; COLOR = the history."""
+        a = np.ascontiguousarray(image, np.uint16)
+        if a.shape != (self.height, self.width, TARGET_CHANNELS[which]):
+            raise ValueError(f"write_target: expected {(self.height, self.width, TARGET_CHANNELS[which])}, got {a.shape}")
+        self._check(lib().rt_write_target(self._h, which, a.ctypes.data_as(C.c_void_p), RT_FORMAT_F16))
+
     def present(self, params, show_motion=False) -> np.ndarray:
         """Present pass over the last frame -> [H, W, 4] uint8 (row 0 = bottom)."""
         pp = make_present_params(params, show_motion, self.width, self.height)
+        out = np.zeros((self.height, self.width, 4), np.uint8)
+        self._check(lib().rt_present(self._h, C.byref(pp), out.ctypes.data_as(_U8P)))
+        return out
+
+    def present_with(self, pp: RtPresentParams) -> np.ndarray:
+        """Present pass with an explicit rt_present.frag uniform block."""
         out = np.zeros((self.height, self.width, 4), np.uint8)
         self._check(lib().rt_present(self._h, C.byref(pp), out.ctypes.data_as(_U8P)))
         return out

@@ -103,6 +103,17 @@ __global__ void k_untile(const void *src, void *dst, FrameGeom g, int channels, 
     }
 }
 
+// Row-major frame of halfs -> this rank's tile-major slots (inverse of k_untile).
+__global__ void k_tile(const void *src, void *dst, FrameGeom g, int channels) {
+    int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= g.nLocalTiles * 256) return;
+    int x, y;
+    if (!pixel_of_slot(g, slot >> 8, slot & 255, x, y)) return;
+    const uint16_t *in = (const uint16_t *)src + ((size_t)y * g.W + x) * channels;
+    uint16_t *out = (uint16_t *)dst + (size_t)slot * channels;
+    for (int c = 0; c < channels; ++c) out[c] = in[c];
+}
+
 // Gathered blocks (rank-major, blockBytes each, tile-major inside) -> row-major frame of halfs.
 __global__ void k_assemble(const void *gathered, void *dst, FrameGeom g, int channels, size_t blockBytes) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -581,6 +592,25 @@ int rt_read_target(RtContext *c, int which, void *dst, int fmt) {
     hipLaunchKernelGGL(k_untile, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, src, c->dStaging, c->g, ch, fmt == RT_FORMAT_F32 ? 1 : 0);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(dst, c->dStaging, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, sync_all(c));
+    return RT_OK;
+}
+
+int rt_write_target(RtContext *c, int which, const void *srcHost, int fmt) {
+    if (!c || !srcHost) return RT_ERR_INVALID;
+    if (!c->sized) return fail(c, RT_ERR_STATE, "rt_write_target before rt_resize");
+    (void)hipSetDevice(c->cfg.device);
+    int ch;
+    void *dstT = target_ptr(c, which, ch);
+    if (!dstT || fmt != RT_FORMAT_F16) return fail(c, RT_ERR_INVALID, "rt_write_target: which=%d format=%d (RT_FORMAT_F16 only)", which, fmt);
+    const size_t bytes = (size_t)c->g.W * c->g.H * ch * 2;
+    HIP_TRY(c, sync_all(c));
+    int rc = ensure_staging(c, bytes);
+    if (rc != RT_OK) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->dStaging, srcHost, bytes, hipMemcpyHostToDevice, c->stream));
+    const unsigned nSlots = (unsigned)c->g.nLocalTiles * 256u;
+    hipLaunchKernelGGL(k_tile, dim3((nSlots + 255) / 256), dim3(256), 0, c->stream, (const void *)c->dStaging, dstT, c->g, ch);
+    HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, sync_all(c));
     return RT_OK;
 }

@@ -789,6 +789,22 @@ int orc_trace_bvh(const OrcUniforms *u, const float *nodes, const float *tris, c
     if (c) { c->nodeFetch = C.nodeFetch; c->triFetch = C.triFetch; c->raysClosest = C.raysClosest; }
     return hit ? 1 : 0;
 }
+// aabbHit (rt_bvh.glsl:124-134) and triHit (:154-170) on their own, for the per-function vectors in tests/golden/glsl_bvh_kat.npz.
+// out4 = {hit, tmin, tmax, 0};  out8 = {hit, t, n.x, n.y, n.z} (t, n only written on a hit, as in the shader).
+void orc_aabb_hit(const float *ro, const float *rd, const float *bmin, const float *bmax, float *out4) {
+    vec3 d = ld3(rd);
+    vec3 rdInv = {1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
+    float a = 0.0f, b = 0.0f;
+    bool h = aabbHit(ld3(ro), rdInv, ld3(bmin), ld3(bmax), a, b);
+    out4[0] = h ? 1.0f : 0.0f; out4[1] = a; out4[2] = b; out4[3] = 0.0f;
+}
+void orc_tri_hit(const OrcUniforms *u, const float *ro, const float *rd, const float *tri12, float tMax, float *out5) {
+    Scene S; S.u = *u;
+    TriSOA T = {{tri12[0], tri12[1], tri12[2]}, {tri12[4], tri12[5], tri12[6]}, {tri12[8], tri12[9], tri12[10]}};
+    float t = 0.0f; vec3 n = v3(0.0f);
+    bool h = triHit(S, ld3(ro), ld3(rd), T, tMax, t, n);
+    out5[0] = h ? 1.0f : 0.0f; out5[1] = t; out5[2] = n.x; out5[3] = n.y; out5[4] = n.z;
+}
 int orc_trace_bvh_shadow(const OrcUniforms *u, const float *nodes, const float *tris, const float *ro, const float *rd, float tMax) {
     Scene S; S.u = *u; S.nodes = nodes; S.tris = tris;
     Counters C;

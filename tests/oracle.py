@@ -206,6 +206,24 @@ def present(pp, targets, nthreads=8):
     return out
 
 
+def aabb_hit(ro, rd, bmin, bmax):
+    out = np.zeros(4, np.float32)
+    f = lib().orc_aabb_hit
+    f.restype = None
+    f.argtypes = [_FP] * 5
+    f(_fp(_f32(ro)), _fp(_f32(rd)), _fp(_f32(bmin)), _fp(_f32(bmax)), _fp(out))
+    return out
+
+
+def tri_hit(u, ro, rd, tri12, tmax):
+    out = np.zeros(5, np.float32)
+    f = lib().orc_tri_hit
+    f.restype = None
+    f.argtypes = [C.POINTER(rt.RtUniforms), _FP, _FP, _FP, C.c_float, _FP]
+    f(C.byref(u), _fp(_f32(ro)), _fp(_f32(rd)), _fp(_f32(tri12)), float(tmax), _fp(out))
+    return out
+
+
 def trace_bvh(u, nodes12, tris12, ro, rd):
     n, t = _f32(nodes12), _f32(tris12)
     ro, rd = _f32(ro), _f32(rd)

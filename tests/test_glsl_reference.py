@@ -1,0 +1,100 @@
+"""The oracle against the REFERENCE's own GLSL, executed in the build container by SwiftShader's software
+OpenGL ES 3.0 (oracle/glsl_ref.py, fixtures written by tests/golden/make_glsl_golden.py).
+
+Each fixture holds complete inputs (uniform bytes, cube map, history) and the shader's outputs.  SwiftShader's
+sin/cos/pow/normalize/dot differ from the oracle's float model in the last bits (no FMA, its own polynomials), so
+agreement is to a tolerance: RMSE < 1e-4 per target (north_star's float tolerance) AND at least 99 % of all values
+bit-identical -- i.e. what differs are isolated pixels next to discontinuities, not a systematic error.
+"""
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import opengl_raytracing_amd as rt
+
+GOLDEN = Path(__file__).resolve().parent / "golden"
+FRAME_FIXTURES = ["glsl_analytic_gradient_64x48", "glsl_analytic_materials_env_48x36", "glsl_analytic_moving_48x36",
+                  "glsl_analytic_toggles_48x36"]
+RMSE_TOL = 1e-4
+EXACT_MIN = 0.99
+
+
+def h2f(a):
+    return a.view(np.float16).astype(np.float32)
+
+
+def check_targets(name, f, got, d):
+    for k, a in zip(("color", "motion", "gpos", "gnrm"), got):
+        b = d[f"{k}{f}"]
+        fa, fb = h2f(a), h2f(b)
+        ok = np.isfinite(fa) & np.isfinite(fb)
+        diff = np.where(ok, fa - fb, 0.0)
+        rmse = float(np.sqrt(np.mean(diff * diff)))
+        exact = float(np.mean(a == b))
+        assert rmse < RMSE_TOL and exact >= EXACT_MIN, (name, f, k, rmse, exact)
+
+
+@pytest.mark.parametrize("name", FRAME_FIXTURES)
+def test_oracle_matches_reference_glsl_frames(orc, name):
+    d = np.load(GOLDEN / f"{name}.npz")
+    env = d["env"] if "env" in d else None
+    prev = None
+    for f in range(d["uniforms"].shape[0]):
+        u = rt.RtUniforms.from_buffer_copy(d["uniforms"][f].tobytes())
+        got, _ = orc.render(u, None, None, env, prev)
+        check_targets(name, f, got, d)
+        prev = d[f"color{f}"]          # the shader's own history, as in the fixture
+
+
+def test_moving_fixture_exercises_reprojection():
+    d = np.load(GOLDEN / "glsl_analytic_moving_48x36.npz")
+    u = rt.RtUniforms.from_buffer_copy(d["uniforms"][1].tobytes())
+    assert u.cameraMoved == 1
+    m = h2f(d["motion1"])
+    assert np.count_nonzero(m) > m.size // 4          # real motion vectors
+    assert (m == 4.0).any()                           # and the disocclusion / sky marker of rt.frag
+
+
+@pytest.mark.parametrize("tag", ["svgf", "plain", "motion", "svgf_moving"])
+def test_oracle_matches_reference_glsl_present(orc, tag):
+    d = np.load(GOLDEN / "glsl_present_48x36.npz")
+    pp = rt.RtPresentParams.from_buffer_copy(d[f"pp_{tag}"].tobytes())
+    targets = [d[f"{k}_{tag}"] for k in ("color", "motion", "gpos", "gnrm")]
+    got = orc.present(pp, targets)
+    want = d[f"rgba_{tag}"]
+    diff = np.abs(got.astype(np.int32) - want.astype(np.int32))
+    assert diff.max() <= 1 and np.mean(got == want) >= 0.995, (tag, diff.max(), np.mean(got == want))
+
+
+def test_oracle_matches_reference_glsl_bvh_primitives(orc):
+    """nodeFetch / triFetch / aabbHit / triHit of rt_bvh.glsl, one call per case (the traversal loops do not run on
+    SwiftShader 4.1: oracle/glsl_ref.py).  Slab tests must agree exactly; Moller-Trumbore t to a median relative error < 1e-6 (the oracle's
+    dot/cross use fmaf, SwiftShader's do not) with the hit decision allowed to differ only on constructed borderline cases."""
+    d = np.load(GOLDEN / "glsl_bvh_kat.npz")
+    nodes, tris, rays, o0, o1, o2 = (d[k] for k in ("nodes12", "tris12", "rays", "o0", "o1", "o2"))
+    n = rays.shape[0]
+    u = orc.frame_uniforms(orc.default_render_params(), orc.default_camera(), 8, 8, 0, True, n, n)
+    assert u.eps == d["eps"]
+    # node decode (rt_bvh.glsl:97-100): left, right, first*8+count as the shader saw them
+    left = np.trunc(nodes[:, 3] + 0.5).astype(np.int64)
+    right = np.trunc(nodes[:, 7] + 0.5).astype(np.int64)
+    first, count = np.trunc(nodes[:, 8] + 0.5).astype(np.int64), np.trunc(nodes[:, 9] + 0.5).astype(np.int64)
+    assert np.array_equal(o0[:, 3].astype(np.int64), left) and np.array_equal(o1[:, 2].astype(np.int64), right)
+    assert np.array_equal(o1[:, 3].astype(np.int64), first * 8 + count)
+    flag_diff, hits, rel = 0, 0, []
+    for i in range(n):
+        a = orc.aabb_hit(rays[i, 0:3], rays[i, 4:7], nodes[i, 0:3], nodes[i, 4:7])
+        assert a[0] == o0[i, 0], i
+        assert (a[1] == o0[i, 1] or (np.isnan(a[1]) and np.isnan(o0[i, 1]))) and (a[2] == o0[i, 2] or (np.isnan(a[2]) and np.isnan(o0[i, 2]))), i
+        t = orc.tri_hit(u, rays[i, 0:3], rays[i, 4:7], tris[i], rays[i, 3])
+        if t[0] != o1[i, 0]:
+            flag_diff += 1
+            continue
+        if t[0]:
+            hits += 1
+            rel.append(abs(t[1] - o1[i, 1]) / abs(o1[i, 1]))
+            assert rel[-1] <= 5e-5, (i, t[1], o1[i, 1])             # grazing triangles (tiny det) amplify the last-bit differences
+            assert np.max(np.abs(t[2:5] - o2[i, 0:3])) <= 1e-6, i
+    assert hits > 100 and flag_diff <= n // 50, (hits, flag_diff)
+    assert np.median(rel) < 1e-6 and np.percentile(rel, 95) < 5e-6

@@ -1,0 +1,58 @@
+"""The HIP path (through the C ABI) against the REFERENCE's own GLSL outputs (tests/golden/glsl_*.npz, produced by
+tests/golden/make_glsl_golden.py: the reference shaders executed by SwiftShader).  Same inputs, same history (handed over
+with rt_write_target), same tolerances as the oracle's check in tests/test_glsl_reference.py -- the product is compared
+with the reference directly, not only through the oracle."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import opengl_raytracing_amd as rt
+from test_glsl_reference import FRAME_FIXTURES, check_targets
+
+pytestmark = pytest.mark.gpu
+GOLDEN = Path(__file__).resolve().parent / "golden"
+
+
+@pytest.fixture(scope="module")
+def ren():
+    r = rt.Renderer()
+    yield r
+    r.close()
+
+
+@pytest.mark.parametrize("name", FRAME_FIXTURES)
+def test_hip_matches_reference_glsl_frames(ren, name):
+    d = np.load(GOLDEN / f"{name}.npz")
+    u0 = rt.RtUniforms.from_buffer_copy(d["uniforms"][0].tobytes())
+    ren.resize(int(u0.resolution[0]), int(u0.resolution[1]))
+    ren.upload_env(d["env"] if "env" in d else None)
+    ren.reset_accum()
+    for f in range(d["uniforms"].shape[0]):
+        u = rt.RtUniforms.from_buffer_copy(d["uniforms"][f].tobytes())
+        if f > 0:
+            ren.write_target(rt.RT_TARGET_COLOR, d[f"color{f - 1}"])      # the shader's own history, as in the fixture
+        ren.render_frame(u)
+        check_targets(name, f, ren.read_all(), d)
+
+
+@pytest.mark.parametrize("tag", ["svgf", "plain", "motion", "svgf_moving"])
+def test_hip_matches_reference_glsl_present(ren, tag):
+    d = np.load(GOLDEN / "glsl_present_48x36.npz")
+    pp = rt.RtPresentParams.from_buffer_copy(d[f"pp_{tag}"].tobytes())
+    ren.resize(48, 36)
+    for which, k in ((rt.RT_TARGET_COLOR, "color"), (rt.RT_TARGET_MOTION, "motion"), (rt.RT_TARGET_GPOS, "gpos"), (rt.RT_TARGET_GNRM, "gnrm")):
+        ren.write_target(which, d[f"{k}_{tag}"])
+    got = ren.present_with(pp)
+    want = d[f"rgba_{tag}"]
+    diff = np.abs(got.astype(np.int32) - want.astype(np.int32))
+    assert diff.max() <= 1 and np.mean(got == want) >= 0.995, (tag, diff.max(), np.mean(got == want))
+
+
+def test_write_target_round_trip(ren):
+    rng = np.random.default_rng(1)
+    ren.resize(70, 37)                                    # ragged: partial tiles on both axes
+    for which, ch in ((rt.RT_TARGET_COLOR, 4), (rt.RT_TARGET_MOTION, 2), (rt.RT_TARGET_GPOS, 4), (rt.RT_TARGET_GNRM, 4)):
+        img = rng.integers(0, 0x7C00, size=(37, 70, ch), dtype=np.uint16)
+        ren.write_target(which, img)
+        assert np.array_equal(ren.read_target(which), img)
