@@ -8,8 +8,12 @@
 // GL semantics encoded here (none are written down in the reference): gl_FragCoord = pixel+0.5,
 // row 0 = bottom row; NEAREST history fetch; non-seamless LINEAR cube map of u8 texels; RNE fp16
 // on every MRT store (src/render/accum.cpp:10,25; src/render/gbuffer.cpp:52-53).
-// Float model: oracle/orc_math.h.  parity unpinned (the reference has no tests or goldens,
-// SURVEY.md section 4): pinned instead by the KATs of SURVEY.md 8c (tests/test_oracle_kat.py).
+// Float model: oracle/orc_math.h.  Parity status: the reference has no tests or goldens; this
+// file is pinned against the reference's own GLSL executed in the build container by SwiftShader (oracle/glsl_ref.py,
+// fixtures tests/golden/glsl_*.npz, checked by tests/test_glsl_reference.py): analytic-scene frames, TAA, motion,
+// materials, cube map, present pass and the BVH primitives (nodeFetch/triFetch/aabbHit/triHit).  The traversal LOOPS
+// of traceBVH/traceBVHShadow cannot be executed by that SwiftShader build and stay "parity unpinned" by execution;
+// they are pinned only by the KATs of SURVEY.md 8c (tests/test_oracle_kat.py).
 #include <algorithm>
 #include <atomic>
 #include <cstdio>

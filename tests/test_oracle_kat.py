@@ -1,7 +1,8 @@
 """Pinning the oracle (CPU, no GPU): the known-answer vectors SURVEY.md 8c derives from the shader text,
 structural KATs, GL-semantics checks, and the committed golden fixtures (tests/golden/).
 
-The reference has no tests, goldens or fixtures for this path ("parity unpinned"), so these are
+The reference has no tests, goldens or fixtures for this path; besides the GLSL-executed fixtures of
+tests/test_glsl_reference.py (which cannot cover the BVH traversal loops: "parity unpinned" there), these are
 the strongest pins available: uint32 RNG KATs are exact; float KATs follow closed forms."""
 import ctypes as C
 import math
@@ -241,3 +242,37 @@ def test_region_and_mask_rendering_is_consistent(orc):
     part, _ = orc.render(u, d["nodes12"], d["tris12"], d["env"], None, mask=mask, nthreads=3)
     m = mask.astype(bool)
     assert np.array_equal(part[0][m], full[0][m]) and not part[0][~m].any()
+
+
+def test_traversal_equals_brute_force_over_the_pinned_primitives(orc):
+    """traceBVH / traceBVHShadow (rt_bvh.glsl:193-304) are the one part of the path the reference's GLSL could not be
+    executed for (tests/test_glsl_reference.py); their primitives aabbHit / triHit are pinned.  The restated loops must
+    then return what an exhaustive sweep with the pinned triHit returns: closest t bit-identical, any-hit identical."""
+    import opengl_raytracing_amd as rt
+    v, f = rt.meshgen.bunny_standin(2)
+    nodes, tris = orc.build_bvh(orc.gather_triangles(v, f))
+    n = tris.shape[0]
+    u = orc.frame_uniforms(orc.default_render_params(), orc.default_camera(), 8, 8, 0, True, nodes.shape[0], n)
+    rng = np.random.default_rng(17)
+    centre = 0.5 * (nodes[0, 0:3] + nodes[0, 4:7])
+    hits = shadowed = 0
+    for k in range(160):
+        ro = (centre + rng.normal(0, 1.0, 3) * 2.0).astype(np.float32)
+        target = tris[rng.integers(n), 0:3] + rng.normal(0, 0.05, 3)
+        rd = (target - ro) / np.linalg.norm(target - ro)
+        rd = rd.astype(np.float32)
+        tmax_shadow = np.float32(rng.uniform(0.5, 6.0))
+        best, best_n, any_hit = np.float32(u.inf), None, False
+        for i in range(n):
+            r = orc.tri_hit(u, ro, rd, tris[i], best)          # closest: tMax = best so far, ties overwrite (rt_bvh.glsl:166,218)
+            if r[0]:
+                best, best_n = r[1], r[2:5].copy()
+            any_hit = any_hit or bool(orc.tri_hit(u, ro, rd, tris[i], tmax_shadow)[0])
+        hit, t, p, nn, _ = orc.trace_bvh(u, nodes, tris, ro, rd)
+        assert hit == (best_n is not None), k
+        if hit:
+            hits += 1
+            assert np.float32(t) == best, (k, t, best)
+        assert orc.trace_bvh_shadow(u, nodes, tris, ro, rd, float(tmax_shadow)) == any_hit, k
+        shadowed += any_hit
+    assert hits > 60 and 20 < shadowed < 160
