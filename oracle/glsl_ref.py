@@ -473,3 +473,75 @@ void main() {
         gl.glDeleteFramebuffers(1, C.byref(fbo))
         self._delete(texs + outs)
         return res
+
+    # ---- the BVH shading branch of rt.frag:92-106 for given hits, with an empty BVH (uNodeCount = 0: traceBVH /
+    # traceBVHShadow return before their loops, so SwiftShader's loop defect is not reached and every shadow / bounce /
+    # AO ray leaves unoccluded).  main() of rt.frag is replaced by one that takes the hit from a texture.
+    _SHADE_MAIN = """
+uniform samplerBuffer uKatRays;   // 3 texels per case: (p, fragX), (n, fragY), (V, seed)
+uniform int uKatWidth;
+void main() {
+    int i = int(gl_FragCoord.x) + int(gl_FragCoord.y) * uKatWidth;
+    vec4 a = texelFetch(uKatRays, 3 * i), b = texelFetch(uKatRays, 3 * i + 1), c = texelFetch(uKatRays, 3 * i + 2);
+    Hit h;
+    h.p = a.xyz; h.n = b.xyz; h.mat = 1; h.t = 1.0;
+    vec3 V = c.xyz;
+    int seed = int(c.w);
+    vec3 radiance = directLightBVH(h, seed, V);
+    if (uEnableGI == 1) radiance += uGiScaleBVH * oneBounceGIBVH(h, uFrameIndex, seed);
+    if (uEnableAO == 1) radiance *= computeAO(h, uFrameIndex);
+    fragColor = vec4(radiance, 1.0);
+    outMotion = vec2(0.0); outGPos = vec4(0.0); outGNrm = vec4(0.0);
+}
+"""
+
+    def shade_bvh_hits(self, u, env_faces, hits12, width):
+        """hits12: n x 12 floats {p, fragX, n, fragY, V, seed} with (fragX, fragY) = centre of pixel i of a `width`-wide grid.
+        -> n x 3 float32 radiance."""
+        gl = self.gl
+        n = hits12.shape[0]
+        W = width
+        H = (n + W - 1) // W
+        if not hasattr(self, "prog_shade"):
+            src = adapt(expand_includes(os.path.join(self.dir, "rt.frag")))
+            cut = src.index("void main()")
+            vs = self._compile_src(GL_VERTEX_SHADER, _FULLSCREEN_VS.encode(), "fullscreen corners")
+            fs = self._compile_src(GL_FRAGMENT_SHADER, (src[:cut] + self._SHADE_MAIN).encode(), "bvh shade kat")
+            self.prog_shade = self._link(vs, fs)
+        hh = np.zeros((W * H, 12), np.float32)
+        hh[:n] = hits12
+        hh[n:, 4:7] = hh[n:, 8:11] = (0.0, 1.0, 0.0)
+        one = np.zeros((1, 12), np.float32)
+        texs = [self._tbo(one), self._tbo(one), self._tbo(hh),
+                self._cube(np.zeros((6, 1, 1, 3), np.uint8) if env_faces is None else env_faces),
+                self._tex2d(GL_RGBA16F, 1, 1, GL_RGBA, GL_HALF_FLOAT, np.zeros((1, 1, 4), np.uint16))]
+        out = self._tex2d(GL_RGBA32F, W, H, GL_RGBA, GL_FLOAT, None)
+        fbo = C.c_uint()
+        gl.glGenFramebuffers(1, C.byref(fbo))
+        gl.glBindFramebuffer(GL_FRAMEBUFFER, fbo)
+        gl.glFramebufferTexture2D(GL_FRAMEBUFFER, GL_COLOR_ATTACHMENT0, GL_TEXTURE_2D, out, 0)
+        bufs = (C.c_uint * 1)(GL_COLOR_ATTACHMENT0)
+        gl.glDrawBuffers(1, bufs)
+        if gl.glCheckFramebufferStatus(GL_FRAMEBUFFER) != GL_FRAMEBUFFER_COMPLETE:
+            raise RuntimeError("shade KAT FBO incomplete")
+        gl.glViewport(0, 0, W, H)
+        p = self.prog_shade
+        gl.glUseProgram(p)
+        self._set_uniforms(p, u)
+        self._bind_sampler(p, "uPrevAccum", 0, GL_TEXTURE_2D, texs[4])
+        self._bind_sampler(p, "uBvhNodes", 1, GL_TEXTURE_2D, texs[0])
+        self._bind_sampler(p, "uBvhTris", 2, GL_TEXTURE_2D, texs[1])
+        self._bind_sampler(p, "uEnvMap", 3, GL_TEXTURE_CUBE_MAP, texs[3])
+        self._bind_sampler(p, "uKatRays", 4, GL_TEXTURE_2D, texs[2])
+        gl.glUniform1i(gl.glGetUniformLocation(p, b"uKatWidth"), W)
+        gl.glDrawArrays(0x0004, 0, 3)
+        gl.glFinish()
+        self._check("shade kat draw")
+        gl.glReadBuffer(GL_COLOR_ATTACHMENT0)
+        buf = np.zeros((H, W, 4), np.float32)
+        gl.glReadPixels(0, 0, W, H, GL_RGBA, GL_FLOAT, buf.ctypes.data_as(C.c_void_p))
+        gl.glBindFramebuffer(GL_FRAMEBUFFER, 0)
+        gl.glDeleteFramebuffers(1, C.byref(fbo))
+        gl.glDeleteTextures(1, C.byref(texs[3]))
+        self._delete(texs[:3] + [texs[4], out])
+        return buf.reshape(-1, 4)[:n, :3].copy()

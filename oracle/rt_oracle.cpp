@@ -809,6 +809,24 @@ void orc_tri_hit(const OrcUniforms *u, const float *ro, const float *rd, const f
     bool h = triHit(S, ld3(ro), ld3(rd), T, tMax, t, n);
     out5[0] = h ? 1.0f : 0.0f; out5[1] = t; out5[2] = n.x; out5[3] = n.y; out5[4] = n.z;
 }
+// The BVH branch of rt.frag:92-106 for a given hit (no traversal: callers pass nodeCount = 0, so every shadow / bounce /
+// AO ray leaves unoccluded): radiance = directLightBVH + giScaleBVH * oneBounceGIBVH, times computeAO.  Per-function
+// vectors for tests/golden/glsl_bvh_shade_kat.npz.  hits: n x 12 floats {p.xyz, fragX, n.xyz, fragY, V.xyz, seed}.
+void orc_shade_bvh_hits(const OrcUniforms *u, const uint8_t *envFaces, int envFaceSize, int envChannels, const float *hits, int n, float *out3) {
+    Scene S; S.u = *u; S.env = envFaces; S.envSize = envFaceSize; S.envCh = envChannels;
+    Counters C;
+    for (int i = 0; i < n; ++i) {
+        const float *q = hits + (size_t)i * 12;
+        Hit h; h.p = {q[0], q[1], q[2]}; h.n = {q[4], q[5], q[6]}; h.mat = 1; h.t = 1.0f;
+        Frag F; F.fc = {q[3], q[7]};
+        vec3 V = {q[8], q[9], q[10]};
+        int seed = (int)q[11];
+        vec3 radiance = directLightBVH(S, C, F, h, seed, V);
+        if (u->enableGI == 1) radiance += u->giScaleBVH * oneBounceGIBVH(S, C, F, h, u->frameIndex, seed);
+        if (u->enableAO == 1) radiance *= computeAO(S, C, F, h, u->frameIndex);
+        out3[i * 3 + 0] = radiance.x; out3[i * 3 + 1] = radiance.y; out3[i * 3 + 2] = radiance.z;
+    }
+}
 int orc_trace_bvh_shadow(const OrcUniforms *u, const float *nodes, const float *tris, const float *ro, const float *rd, float tMax) {
     Scene S; S.u = *u; S.nodes = nodes; S.tris = tris;
     Counters C;

@@ -166,6 +166,35 @@ def main():
     print("  bvh primitives:", n, "cases;", {k: int(v) for k, v in agree.items()})
     np.savez_compressed(HERE / "glsl_bvh_kat.npz", nodes12=nodes[:n], tris12=tris[:n], rays=rays, eps=np.float32(eps), o0=o0, o1=o1, o2=o2)
 
+    # G. the BVH shading branch (rt.frag:92-106: directLightBVH + oneBounceGIBVH + computeAO) for synthetic hits, empty BVH
+    W = 32
+    nh = 512
+    rng = np.random.default_rng(23)
+    hits = np.zeros((nh, 12), np.float32)
+    for i in range(nh):
+        nrm = rng.normal(size=3); nrm /= np.linalg.norm(nrm)
+        if i % 3 == 0:
+            nrm = np.array([0.0, 1.0, 0.0]) + rng.normal(0, 0.2, 3); nrm /= np.linalg.norm(nrm)   # mostly facing the disk light
+        vdir = nrm + rng.normal(0, 0.7, 3); vdir /= np.linalg.norm(vdir)
+        hits[i, 0:3] = np.array([-2.0, 1.5, 0.0]) + rng.normal(0, 1.0, 3)
+        hits[i, 3], hits[i, 7] = (i % W) + 0.5, (i // W) + 0.5
+        hits[i, 4:7] = nrm * (1.0 if i % 4 else 2.5)          # un-normalised normals too: the shader normalises (rt_lighting.glsl:406)
+        hits[i, 8:11] = vdir
+        hits[i, 11] = float(i % 7)
+    shade = {"hits": hits, "env": faces, "width": np.int32(W)}
+    for tag, kw in (("default", {}), ("disk_light_only", dict(sunEnabled=0, pointLightEnabled=0, skyEnabled=0)), ("no_env_gi_only", dict(enableEnvMap=0, enableAO=0))):
+        p = orc.default_render_params(); p.sppPerFrame = 2
+        for k, val in kw.items():
+            setattr(p, k, val)
+        u = orc.frame_uniforms(p, orc.default_camera(), W, nh // W, 3, True, 0, 0, env_loaded=(p.enableEnvMap == 1))
+        got = g.shade_bvh_hits(u, faces if p.enableEnvMap == 1 else None, hits, W)
+        want = orc.shade_bvh_hits(u, faces if p.enableEnvMap == 1 else None, hits)
+        rel = np.abs(got - want) / np.maximum(np.abs(want), 1e-3)
+        print(f"  bvh shade {tag}: bit-exact {np.mean(got == want):.4f}  max rel {rel.max():.3e}  median rel {np.median(rel):.3e}  mean radiance {want.mean():.4f}")
+        shade[f"u_{tag}"] = ubytes(u)
+        shade[f"rad_{tag}"] = got
+    np.savez_compressed(HERE / "glsl_bvh_shade_kat.npz", **shade)
+
 
 if __name__ == "__main__":
     main()

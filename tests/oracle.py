@@ -224,6 +224,18 @@ def tri_hit(u, ro, rd, tri12, tmax):
     return out
 
 
+def shade_bvh_hits(u, env_faces, hits12):
+    """rt.frag's BVH shading branch for given hits with an empty BVH (see orc_shade_bvh_hits) -> n x 3 float32."""
+    h = _f32(hits12).reshape(-1, 12)
+    out = np.zeros((h.shape[0], 3), np.float32)
+    e = None if env_faces is None else np.ascontiguousarray(env_faces, np.uint8)
+    f = lib().orc_shade_bvh_hits
+    f.restype = None
+    f.argtypes = [C.POINTER(rt.RtUniforms), _U8P, C.c_int, C.c_int, _FP, C.c_int, _FP]
+    f(C.byref(u), None if e is None else e.ctypes.data_as(_U8P), 0 if e is None else e.shape[1], 0 if e is None else e.shape[3], _fp(h), h.shape[0], _fp(out))
+    return out
+
+
 def trace_bvh(u, nodes12, tris12, ro, rd):
     n, t = _f32(nodes12), _f32(tris12)
     ro, rd = _f32(ro), _f32(rd)

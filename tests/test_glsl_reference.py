@@ -98,3 +98,17 @@ def test_oracle_matches_reference_glsl_bvh_primitives(orc):
             assert np.max(np.abs(t[2:5] - o2[i, 0:3])) <= 1e-6, i
     assert hits > 100 and flag_diff <= n // 50, (hits, flag_diff)
     assert np.median(rel) < 1e-6 and np.percentile(rel, 95) < 5e-6
+
+
+@pytest.mark.parametrize("tag", ["default", "disk_light_only", "no_env_gi_only"])
+def test_oracle_matches_reference_glsl_bvh_shading(orc, tag):
+    """rt.frag:92-106 (directLightBVH + giScaleBVH * oneBounceGIBVH, times computeAO) for 512 given hits with an empty BVH,
+    executed by the reference GLSL (fp32 outputs, no fp16 rounding to hide behind): relative error < 5e-5, median < 1e-6."""
+    d = np.load(GOLDEN / "glsl_bvh_shade_kat.npz")
+    u = rt.RtUniforms.from_buffer_copy(d[f"u_{tag}"].tobytes())
+    assert u.useBVH == 1 and u.nodeCount == 0
+    got = orc.shade_bvh_hits(u, d["env"] if u.useEnvMap == 1 else None, d["hits"])
+    want = d[f"rad_{tag}"]
+    rel = np.abs(got - want) / np.maximum(np.abs(want), 1e-3)
+    assert rel.max() < 5e-5 and np.median(rel) < 1e-6, (tag, rel.max(), np.median(rel))
+    assert want.mean() > 0.05 and np.count_nonzero(want) > want.size // 2
