@@ -183,7 +183,7 @@ struct PrimarySrc {   // ray i = primary ray of candidate i
     int *outTri;
     RT_DEV void prepare() {}
     RT_DEV uint32_t size() const { return *count; }
-    RT_DEV bool load(uint32_t i, V3 &ro, V3 &rd, float &tMax, uint32_t &token) const {
+    RT_DEV bool load(uint32_t i, V3 &ro, V3 &rd, float &tMax, uint32_t &token, bool) const {
         token = i;
         int px, py;
         slot_to_pixel(fr->g, cand[i], px, py);
@@ -207,10 +207,22 @@ struct QueueSrc {     // slot-major queue: ray r -> (slot = r / n, j = r % n) at
     RT_DEV void prepare() { uint32_t h = *liveCount; nLive = min(h, c0 + cap) - min(h, c0); }   // no wrapping subtraction, see chunk_live
     RT_DEV uint32_t size() const { return nLive * slots; }
     RT_DEV uint32_t addr(uint32_t r) const { return (r / nLive) * stride + (r % nLive); }
-    RT_DEV bool load(uint32_t r, V3 &ro, V3 &rd, float &tMax, uint32_t &token) const {
+    // spec: the caller expects most of this batch to be live (the previous batch of the run was): fetch the 32-byte record
+    // together with the liveness word -- one gather round trip instead of two dependent ones.  Otherwise probe first: runs of
+    // dead slots (e.g. the disk-light samples of surfaces facing away from the light) then never touch their records.
+    RT_DEV bool load(uint32_t r, V3 &ro, V3 &rd, float &tMax, uint32_t &token, bool spec) const {
         uint32_t a = addr(r);
         token = a;                       // results go to the same queue address: no second div/mod at retirement
-        tMax = tm[a];                    // 4-byte, coalesced liveness probe: dead slots never touch the 32-byte record
+        if (spec) {
+            float t = tm[a];
+            float4 oo = o[a];
+            float4 dd = d[a];
+            asm volatile("" : "+v"(t), "+v"(oo.x), "+v"(oo.y), "+v"(oo.z), "+v"(dd.x), "+v"(dd.y), "+v"(dd.z));
+            tMax = t;
+            ro = f4xyz(oo); rd = f4xyz(dd);
+            return !(t < 0.0f);
+        }
+        tMax = tm[a];                    // 4-byte, coalesced liveness probe
         if (tMax < 0.0f) return false;
         float4 oo = o[a];
         float4 dd = d[a];
@@ -228,9 +240,9 @@ struct DualQueueSrc {
     uint32_t na;
     RT_DEV void prepare() { a.prepare(); b.prepare(); na = a.size(); }
     RT_DEV uint32_t size() const { return na + b.size(); }
-    RT_DEV bool load(uint32_t r, V3 &ro, V3 &rd, float &tMax, uint32_t &token) const {
-        if (r < na) return a.load(r, ro, rd, tMax, token);
-        bool live = b.load(r - na, ro, rd, tMax, token);
+    RT_DEV bool load(uint32_t r, V3 &ro, V3 &rd, float &tMax, uint32_t &token, bool spec) const {
+        if (r < na) return a.load(r, ro, rd, tMax, token, spec);
+        bool live = b.load(r - na, ro, rd, tMax, token, spec);
         token |= 0x80000000u;             // results of the second queue (addresses stay below 2^31: checked on the host)
         return live;
     }
@@ -272,7 +284,10 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
     src.prepare();
     const uint32_t n = src.size();
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t runLen = (uint32_t)max(tune.chunk, 8);
+    // run length: RT_CHUNK, else about a third of a wave's share of the queue, in [128, 256] rays (measured on MI355X, 1080p / 4 spp:
+    // whole frame 2.42 / 2.26 / 2.18 / 2.20 ms with runs of 64 / 128 / 256 / 512; one rank of eight 0.51 / 0.48 / 0.52 / 0.55)
+    const uint32_t runLen = tune.chunk > 0 ? (uint32_t)max(tune.chunk, 8)
+                                           : min(256u, max(128u, ((n / (3u * 4u * gridDim.x) + 63u) / 64u) * 64u));
 
     // per-lane ray state
     V3 ro = mk3(0.0f), rd = mk3(0.0f), rdInv = mk3(0.0f);
@@ -286,6 +301,7 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
     uint32_t runNext = 0, runEnd = 0;   // wave-uniform: the part of the current run not handed out yet
     const uint32_t shard = (blockIdx.x * 4u + (threadIdx.x >> 6)) % kShards;   // home shard of this wave
     bool homeDry = false;
+    bool specLoad = false;              // wave-uniform: most rays of the previous batch were live
     const uint32_t nRuns = (n + runLen - 1u) / runLen;
 
     // pop the next subtree of this lane's ray, or retire the ray
@@ -351,14 +367,16 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
                 runEnd = (uint32_t)min((unsigned long long)n, base + runLen);
             }
             const uint32_t take = min((uint32_t)nIdle, runEnd - runNext);
+            bool drewLive = false;
             if (!active) {
                 uint32_t rank = (uint32_t)__popcll(idleMask & ((1ull << lane) - 1ull));
                 if (rank < take) {
                     uint32_t my = runNext + rank;
                     float tMax;
                     uint32_t token;
-                    const bool liveRay = src.load(my, ro, rd, tMax, token);
+                    const bool liveRay = src.load(my, ro, rd, tMax, token, specLoad);
                     rayId = token;
+                    drewLive = liveRay;
                     if (liveRay) {
                         traced++;
                         rdInv = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
@@ -375,6 +393,7 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
                 }
             }
             runNext += take;
+            specLoad = (uint32_t)__popcll(__ballot(drewLive)) * 2u >= take;
             if (STATS && lane == 0) st_[10] += clock64() - tR_;
             continue;   // lanes that drew a dead slot or a root miss may draw again
         }
@@ -715,7 +734,7 @@ struct RtWave {
     std::string err;
     int cus = 256;
     size_t budgetBytes = (size_t)8 << 30;   // ray-queue budget per context; 288 GB of HBM make this cheap
-    TraceTune tune{32, 16, 64, 2, 0};
+    TraceTune tune{32, 16, 0, 2, 0};   // chunk 0 = run length chosen in the kernel from the queue size
     // allocations
     size_t slotsCap = 0;      // per-frame arrays sized for this many pixel slots
     size_t chunkBytes = 0;    // bytes of the per-chunk arena
@@ -832,7 +851,10 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
     rt_stage_begin(ctx, ST_TRACE_PRIMARY, st);
     PrimarySrc ps;
     ps.fr = dFrame; ps.cand = wb.cand; ps.count = &wb.counts[0]; ps.outT = wb.primT; ps.outTri = wb.primTri;
-    launch_trace<PrimarySrc, false>(st, traceBlocks, treeDepth, dFrame, host.sc, ps, &wb.heads[0], &wb.counts[2], tune, S ? S + 0 : nullptr);
+    TraceTune tuneP = tune;   // primary rays: one run = one 8x8 pixel block; their cost varies strongly across the screen, so short runs
+    if (tuneP.chunk == 0) tuneP.chunk = 64;   // balance the tail (stage alone 0.50 / 0.62 / 0.86 ms with runs of 64 / 128 / 256)
+    if (const char *e = getenv("RT_CHUNK_PRIMARY")) tuneP.chunk = atoi(e);
+    launch_trace<PrimarySrc, false>(st, traceBlocks, treeDepth, dFrame, host.sc, ps, &wb.heads[0], &wb.counts[2], tuneP, S ? S + 0 : nullptr);
     rt_stage_end(ctx, ST_TRACE_PRIMARY, 1, st);
 
     rt_stage_begin(ctx, ST_POST_PRIMARY, st);
