@@ -197,6 +197,29 @@ SIGNATURES = {
 }
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so / libhsa-runtime64.so (same
+    SONAMEs as /opt/rocm's, found through libtorch's RPATH under a different file name).  If librt_mi355.so pulled in
+    /opt/rocm's copy first, a later `import torch` (FrameGatherer, a user's own code) would load the bundled copy as a
+    second runtime and fail with "No HIP GPUs are available".  When a torch wheel with bundled libraries is installed,
+    load those first (no `import torch`); librt_mi355.so's NEEDED entries then bind to them by SONAME."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    d = Path(list(spec.submodule_search_locations)[0]) / "lib"
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        f = d / name
+        if f.exists():
+            try:
+                C.CDLL(str(f), mode=C.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
 def lib():
     """Load librt_mi355.so (built by `make -C opengl-raytracing_amd` / __graft_entry__.build())."""
     global _lib
@@ -205,6 +228,7 @@ def lib():
     if not LIB_PATH.exists():
         raise RtError(RT_ERR_NO_DEVICE, f"{LIB_PATH} is not built; run __graft_entry__.build() (hipcc --offload-arch=gfx950). "
                                         "There is no CPU fallback.")
+    _share_torch_hip_runtime()
     L = C.CDLL(str(LIB_PATH))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(L, name)

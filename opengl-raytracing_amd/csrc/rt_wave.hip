@@ -294,6 +294,7 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
     float tBest = 0.0f;          // closest: best t so far; any: tMax
     int triBest = -1;
     int ref = 0, sp = 0;
+    int leaf = 0;                // any-hit only: one postponed leaf (0 = none; leaf refs are negative)
     uint32_t rayId = 0;
     bool active = false;
     bool exhausted = (n == 0);
@@ -310,7 +311,9 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
         while (sp > 0) {
             sp--;
             if constexpr (ANY) {
-                ref = (int)stk[sp * 64];
+                const int r = (int)stk[sp * 64];
+                if (r < 0 && leaf == 0) { leaf = r; continue; }   // leaves wait in `leaf`; keep looking for an inner node
+                ref = r;                                          // an inner node, or a second leaf (the lane then waits)
                 found = true;
                 break;
             } else {
@@ -322,9 +325,13 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
             }
         }
         if (!found) {
-            if (ANY) src.store_any(rayId, false);
-            else src.store_closest(rayId, triBest >= 0 ? tBest : inf, triBest);
-            active = false;
+            if constexpr (ANY) {
+                ref = RT_NO_CHILD;
+                if (leaf == 0) { src.store_any(rayId, false); active = false; }   // else: the postponed leaf is all that is left
+            } else {
+                src.store_closest(rayId, triBest >= 0 ? tBest : inf, triBest);
+                active = false;
+            }
         }
     };
 
@@ -383,7 +390,9 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
                         tBest = ANY ? tMax : inf;
                         triBest = -1;
                         sp = 0;
+                        leaf = 0;
                         ref = ANY ? sc.rootRef4 : sc.rootRef;
+                        if (ANY && ref < 0) { leaf = ref; ref = RT_NO_CHILD; }   // single-leaf tree
                         float tmin;
                         bool in = sc.hasBVH && !tune.skipTraversal && slab(ro, rdInv, ld3(sc.rootMin), ld3(sc.rootMax), tmin) && !(tmin > tBest);
                         if (in) active = true;
@@ -403,10 +412,10 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
         }
         // ---- phase 1: walk inner nodes until (almost) every live lane holds a leaf
         for (;;) {
-            const bool searching = active && ref >= 0;
+            const bool searching = active && (uint32_t)ref < (uint32_t)RT_NO_CHILD;   // an inner node in hand
             const unsigned long long sm = __ballot(searching);
             if (sm == 0ull) break;
-            if (__popcll(sm) < tune.minSearch && __ballot(active && ref < 0) != 0ull) break;   // keep the leaf phase dense
+            if (__popcll(sm) < tune.minSearch && __ballot(active && (ANY ? leaf != 0 : ref < 0)) != 0ull) break;   // keep the leaf phase dense
             const unsigned long long tI_ = STATS ? clock64() : 0ull;
             if (STATS && lane == 0) { st_[3]++; st_[4] += (unsigned long long)__popcll(sm); }
             if (searching) {
@@ -424,11 +433,19 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
                     // loads are issued up front and the four tests are branch-free (no dependent "is there a child" round trip)
                     bool h2 = slab(ro, rdInv, f4xyz(q4), f4xyz(q5), t2) && t2 <= tBest;
                     bool h3 = slab(ro, rdInv, f4xyz(q6), f4xyz(q7), t3) && t3 <= tBest;
+                    // Any-hit order is free, so leaves are postponed: the first leaf met goes to `leaf`, the lane goes on with an
+                    // inner child (or pops one), and leaves are tested in the leaf phase when (nearly) every lane holds one --
+                    // both phases run with more lanes busy than when a lane stops at its first leaf.
                     int nxt = RT_NO_CHILD;
-                    if (h0) nxt = r0;
-                    if (h1) { if (nxt == RT_NO_CHILD) nxt = r1; else { stk[sp * 64] = (uint32_t)r1; sp++; } }
-                    if (h2) { if (nxt == RT_NO_CHILD) nxt = r2; else { stk[sp * 64] = (uint32_t)r2; sp++; } }
-                    if (h3) { if (nxt == RT_NO_CHILD) nxt = r3; else { stk[sp * 64] = (uint32_t)r3; sp++; } }
+                    auto take = [&](bool h, int r) {
+                        if (!h) return;
+                        if (r < 0 && leaf == 0) { leaf = r; return; }
+                        if (nxt == RT_NO_CHILD) { nxt = r; return; }
+                        if (r >= 0 && nxt < 0) { const int t = nxt; nxt = r; r = t; }   // go on with the inner node, defer the leaf
+                        stk[sp * 64] = (uint32_t)r;
+                        sp++;
+                    };
+                    take(h0, r0); take(h1, r1); take(h2, r2); take(h3, r3);
                     if (nxt == RT_NO_CHILD) pop_or_finish();
                     else ref = nxt;
                 } else {
@@ -456,10 +473,11 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
         }
         // ---- phase 2: leaves
         const unsigned long long tL_ = STATS ? clock64() : 0ull;
-        if (STATS) { unsigned long long lm = __ballot(active && ref < 0); if (lane == 0 && lm) { st_[5]++; st_[6] += (unsigned long long)__popcll(lm); } }
-        if (active && ref < 0) {
+        const int leafNow = ANY ? leaf : ref;   // any-hit: the postponed leaf; closest: the leaf the walk stopped at
+        if (STATS) { unsigned long long lm = __ballot(active && leafNow < 0); if (lane == 0 && lm) { st_[5]++; st_[6] += (unsigned long long)__popcll(lm); } }
+        if (active && leafNow < 0) {
             if (STATS) st_[1]++;
-            int v = -ref - 1;
+            int v = -leafNow - 1;
             int first = v >> 3, count = (v & 7) + 1;
             bool done = false;
             // Triangle records of a leaf are contiguous: fetch them LEAFB at a time so that the ~0.4-0.8 us gather
@@ -484,6 +502,10 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
             if (ANY && done) {
                 src.store_any(rayId, true);
                 active = false;
+            } else if constexpr (ANY) {
+                leaf = 0;
+                if (ref < 0) { leaf = ref; ref = RT_NO_CHILD; }        // a second leaf was waiting in `ref`
+                if (ref == RT_NO_CHILD) pop_or_finish();               // look for an inner node (retires the ray if nothing is left)
             } else pop_or_finish();
         }
         if (STATS && lane == 0) st_[9] += clock64() - tL_;
