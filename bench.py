@@ -31,6 +31,7 @@ for p in (str(ROOT), str(ROOT / "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+L1_GATHER_PEAK_G = 256 * 2.4   # G lane-loads/s: one divergent 16-byte lane-load per clock and CU (tools/gather.hip)
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 W, H, SPP = 1920, 1080, 4
 
@@ -154,7 +155,7 @@ def main():
         frames_all = max(int(tr[1].item()) // world, 1)
         traced_per_frame = int(tr[0].item()) * steps // frames_all // steps if traced.frames else 0
         return {"seconds": float(tt.item()), "counters": total, "local_counters": cnt, "stages": stages,
-                "traced_per_frame": traced_per_frame}
+                "traced_per_frame": traced_per_frame, "traced": traced}
 
     closeup = run_camera(scenes.camera("closeup"), args.steps, args.warmup)
     # serial stage breakdown (one frame in flight): in the timed run up to 3-4 frames overlap, which stretches every kernel's
@@ -226,15 +227,27 @@ def main():
                     per_frame = v["hbm_bytes_per_frame_corrected"]
                     traffic = per_frame * args.steps / launches
                     traffic_src = "profiles/r01_wavefront_traffic.json"
+        # The bound these kernels really run against: divergent per-lane gathers go through a CU's L1 at one 16-byte lane-load per
+        # clock (tools/gather.hip, profiles/r01_gather_microbench.txt: 591 G lane-loads/s measured chip-wide, 256 CUs x 2.4 GHz =
+        # 614 G/s in the model).  The traversal kernels count the node / triangle gather loads they issue (RtTracedRays.gatherLoads*).
+        l1 = None
+        tr = res["traced"]
+        gl = {"trace_primary": tr.gatherLoadsPrimary, "trace_shadow": tr.gatherLoadsShadow, "trace_gi": tr.gatherLoadsBounce}
+        if name in gl and tr.frames:
+            per_launch = gl[name] / tr.frames * args.steps / launches
+            rate = per_launch / (avg_ms * 1e-3) / 1e9
+            l1 = {"unit": "G lane-loads/s (16 B each)", "lane_loads_per_launch": per_launch, "achieved": rate, "peak": L1_GATHER_PEAK_G,
+                  "frac": rate / L1_GATHER_PEAK_G, "bytes_per_s_TB": rate * 16 / 1e3,
+                  "peak_source": "256 CUs x 2.4 GHz x 1 lane-load/clk; tools/gather.hip measures 591 G/s for 64 lanes x 4 x dwordx4 from a 1 MB table"}
         roofline = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                     "avg_launch_ms": avg_ms, "launches": launches, "algorithmic_bytes_per_launch": bytes_per_launch,
-                    "attribution": attribution,
+                    "attribution": attribution, "l1_gather": l1,
                     "avg_launch_ms_source": "HIP events, one frame in flight" if overlapped_span_ms is not None else "HIP events, timed region",
                     "event_span_ms_with_frames_overlapping": overlapped_span_ms,
                     "note": "BVH (1 MB nodes + 3.9 MB tris) is L2/Infinity-Cache resident and the reference layout fetches 3x48 B per node visit, "
-                            "so algorithmic bytes/s exceed the HBM peak (frac > 1) while measured HBM traffic is ~7% of peak: the kernel is bound by "
-                            "vector-cache gather rate/latency, see DESIGN.md 4.3 and profiles/README.md"}
+                            "so algorithmic bytes/s exceed the HBM peak (frac > 1) while measured HBM traffic is ~8% of peak: the kernel is bound by "
+                            "the L1 gather rate (l1_gather), see DESIGN.md 4.3 and profiles/README.md"}
 
     out = {
         "metric": "Mray/s @1080p 4spp bunny BVH", "value": mray, "unit": "Mray/s", "n_gpus": world, "steps": args.steps,

@@ -210,8 +210,13 @@ int rt_reset_counters(RtContext *ctx);
 
 /* Rays the wavefront pipeline actually traversed since the last reset (identical rays of the reference -- the SPP
  * copies of a primary ray, the per-sample copies of the AO rays -- are traced once; disk-light shadow rays whose
- * weight is exactly zero are not traced at all).  RtCounters keeps counting in the reference's units. */
-typedef struct RtTracedRays { uint64_t candidatePixels, hitPixels, primary, shadow, bounce, bounceShadow, frames; } RtTracedRays;
+ * weight is exactly zero are not traced at all).  RtCounters keeps counting in the reference's units.
+ * gatherLoads*: 16-byte per-lane gather loads (BVH node and triangle records) the three traversal launches issued -- the unit of
+ * the L1 gather roofline they run against (one divergent 16-byte lane-load per clock and CU, tools/gather.hip). */
+typedef struct RtTracedRays {
+    uint64_t candidatePixels, hitPixels, primary, shadow, bounce, bounceShadow, frames;
+    uint64_t gatherLoadsPrimary, gatherLoadsShadow, gatherLoadsBounce;
+} RtTracedRays;
 int rt_get_traced_rays(RtContext *ctx, RtTracedRays *out, int reset);
 
 /* Device timing of the dominant kernel(s): HIP events recorded on the context's stream around each

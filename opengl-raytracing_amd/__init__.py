@@ -123,7 +123,8 @@ class RtStageTimes(_Struct):
 
 
 class RtTracedRays(_Struct):
-    _fields_ = [(n, C.c_uint64) for n in ("candidatePixels", "hitPixels", "primary", "shadow", "bounce", "bounceShadow", "frames")]
+    _fields_ = [(n, C.c_uint64) for n in ("candidatePixels", "hitPixels", "primary", "shadow", "bounce", "bounceShadow", "frames",
+                                             "gatherLoadsPrimary", "gatherLoadsShadow", "gatherLoadsBounce")]
 
     @property
     def rays(self):

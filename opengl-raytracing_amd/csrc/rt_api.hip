@@ -690,16 +690,17 @@ int rt_reset_counters(RtContext *c) {
 int rt_get_traced_rays(RtContext *c, RtTracedRays *out, int reset) {
     if (!c || !out) return RT_ERR_INVALID;
     (void)hipSetDevice(c->cfg.device);
-    unsigned long long v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long v[16] = {0};
     (void)sync_all(c);
     for (int i = 0; i < c->nLanes; ++i) {
-        unsigned long long t[8];
+        unsigned long long t[16];
         int rc = rt_wave_traced(c->wave[i], c->lanes[i], t, reset != 0);
         if (rc != RT_OK) return fail(c, rc, "rt_get_traced_rays: %s", rt_wave_error(c->wave[i]));
-        for (int k = 0; k < 8; ++k) v[k] += t[k];
+        for (int k = 0; k < 16; ++k) v[k] += t[k];
     }
     out->candidatePixels = v[0]; out->hitPixels = v[1]; out->primary = v[2]; out->shadow = v[3]; out->bounce = v[4];
     out->bounceShadow = v[5]; out->frames = v[6];
+    out->gatherLoadsPrimary = v[8]; out->gatherLoadsShadow = v[9]; out->gatherLoadsBounce = v[10];
     return RT_OK;
 }
 

@@ -269,7 +269,8 @@ template <> struct StackOf<true> { typedef uint32_t type; };              // any
 
 template <class Src, bool ANY, int STACK, int LEAFB, bool STATS = false>
 __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, const float4 *__restrict__ wnodes, const float4 *__restrict__ tris, Src src,
-                                                uint32_t *head, uint32_t *tally, TraceTune tune, unsigned long long *stats = nullptr) {
+                                                uint32_t *head, uint32_t *tally, unsigned long long *gatherLoads, TraceTune tune,
+                                                unsigned long long *stats = nullptr) {
     // STATS (diagnostic build only, RT_TRACE_STATS=1): [0] inner-node visits [1] leaf visits [2] triangle tests [3] inner-phase wave
     // iterations [4] active lanes summed over them [5] leaf-phase wave iterations [6] lanes with a leaf summed [7] refill rounds
     unsigned long long st_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // [8] cycles in inner steps [9] in leaf phases [10] in refills [11] wave lifetime
@@ -299,6 +300,7 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
     bool active = false;
     bool exhausted = (n == 0);
     uint32_t traced = 0;
+    uint32_t gathers = 0;        // 16-byte gather loads this lane issued for nodes and triangles (the L1 gather roofline's unit)
     uint32_t runNext = 0, runEnd = 0;   // wave-uniform: the part of the current run not handed out yet
     const uint32_t shard = (blockIdx.x * 4u + (threadIdx.x >> 6)) % kShards;   // home shard of this wave
     bool homeDry = false;
@@ -420,6 +422,7 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
             if (STATS && lane == 0) { st_[3]++; st_[4] += (unsigned long long)__popcll(sm); }
             if (searching) {
                 if (STATS) st_[0]++;
+                gathers += ANY ? 8u : 4u;
                 if constexpr (ANY) {
                     // 4-wide node: up to four grandchild boxes per 128-byte record, order irrelevant for any-hit
                     const float4 *nd = nodes + (size_t)ref * 8;
@@ -484,6 +487,7 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
             // round trips of one group overlap (the array is padded, so no bounds branch); test in leaf order.
             for (int i = 0; i < count && !done; i += LEAFB) {
                 const float4 *t = sc.tris + (size_t)(first + i) * 3;
+                gathers += 3u * LEAFB;
                 float4 rec[LEAFB][3];
 #pragma unroll
                 for (int k = 0; k < LEAFB; ++k) { rec[k][0] = t[k * 3 + 0]; rec[k][1] = t[k * 3 + 1]; rec[k][2] = t[k * 3 + 2]; }
@@ -522,6 +526,11 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
         uint32_t s = traced;
         for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
         if (lane == 0 && s) atomicAdd(tally, s);
+    }
+    if (gatherLoads) {
+        unsigned long long g = gathers;
+        for (int off = 32; off > 0; off >>= 1) g += __shfl_down(g, off, 64);
+        if (lane == 0 && g) atomicAdd(gatherLoads, g);
     }
 }
 
@@ -727,8 +736,8 @@ __global__ void k_accum_tally(const uint32_t *counts, unsigned long long *acc) {
 }
 
 template <class Src, bool ANY>
-void launch_trace(hipStream_t st, int cus, int depth, const DevFrame *fr, const DevScene &hs, Src src, uint32_t *head, uint32_t *tally, TraceTune tune,
-                  unsigned long long *stats = nullptr) {
+void launch_trace(hipStream_t st, int cus, int depth, const DevFrame *fr, const DevScene &hs, Src src, uint32_t *head, uint32_t *tally,
+                  unsigned long long *gatherLoads, TraceTune tune, unsigned long long *stats = nullptr) {
     // Stack entries: closest-hit defers one sibling per binary level (8 B each); any-hit walks 4-wide nodes and can
     // defer three per two levels (4 B each).  Resident 256-thread blocks per CU follow from the LDS footprint.
     const int need = ANY ? 3 * ((depth + 1) / 2) : depth;
@@ -737,8 +746,8 @@ void launch_trace(hipStream_t st, int cus, int depth, const DevFrame *fr, const 
     const int perCU = std::max(1, std::min(8, (160 * 1024) / (256 * stack * (ANY ? 4 : 8))));
     const float4 *nodes = ANY ? hs.w4 : hs.wnodes;
     dim3 g((unsigned)(cus * perCU)), b(256);
-#define RT_LAUNCH_TRACE(ST, LB) do { if (stats) hipLaunchKernelGGL((k_trace<Src, ANY, ST, LB, true>), g, b, 0, st, fr, nodes, hs.tris, src, head, tally, tune, stats); \
-        else hipLaunchKernelGGL((k_trace<Src, ANY, ST, LB, false>), g, b, 0, st, fr, nodes, hs.tris, src, head, tally, tune, (unsigned long long *)nullptr); } while (0)
+#define RT_LAUNCH_TRACE(ST, LB) do { if (stats) hipLaunchKernelGGL((k_trace<Src, ANY, ST, LB, true>), g, b, 0, st, fr, nodes, hs.tris, src, head, tally, gatherLoads, tune, stats); \
+        else hipLaunchKernelGGL((k_trace<Src, ANY, ST, LB, false>), g, b, 0, st, fr, nodes, hs.tris, src, head, tally, gatherLoads, tune, (unsigned long long *)nullptr); } while (0)
 #define RT_LAUNCH_TRACE_LB(ST) do { if (tune.leafb >= 4) RT_LAUNCH_TRACE(ST, 4); else if (tune.leafb >= 2) RT_LAUNCH_TRACE(ST, 2); else RT_LAUNCH_TRACE(ST, 1); } while (0)
     if (stack == s0) RT_LAUNCH_TRACE_LB((ANY ? 24 : 16));
     else if (stack == s1) RT_LAUNCH_TRACE_LB((ANY ? 36 : 24));
@@ -807,7 +816,7 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
     const int S1 = A + 6 * SPP, S2 = 6 * SPP;
 
     if (!w->counts) { W_TRY(hipMalloc(&w->counts, (64 + 4096) * sizeof(uint32_t))); W_TRY(hipMalloc(&w->heads, (size_t)kMaxLaunches * kHeadWords * sizeof(uint32_t)));
-        W_TRY(hipMalloc(&w->acc, 8 * sizeof(unsigned long long))); W_TRY(hipMemsetAsync(w->acc, 0, 8 * sizeof(unsigned long long), st)); }
+        W_TRY(hipMalloc(&w->acc, 16 * sizeof(unsigned long long))); W_TRY(hipMemsetAsync(w->acc, 0, 16 * sizeof(unsigned long long), st)); }
     // per-frame arena: cand, primT, primTri, hits
     if (w->slotsCap < nSlots) {
         if (w->frameArena) (void)hipFree(w->frameArena);
@@ -876,7 +885,7 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
     TraceTune tuneP = tune;   // primary rays: one run = one 8x8 pixel block; their cost varies strongly across the screen, so short runs
     if (tuneP.chunk == 0) tuneP.chunk = 64;   // balance the tail (stage alone 0.50 / 0.62 / 0.86 ms with runs of 64 / 128 / 256)
     if (const char *e = getenv("RT_CHUNK_PRIMARY")) tuneP.chunk = atoi(e);
-    launch_trace<PrimarySrc, false>(st, traceBlocks, treeDepth, dFrame, host.sc, ps, &wb.heads[0], &wb.counts[2], tuneP, S ? S + 0 : nullptr);
+    launch_trace<PrimarySrc, false>(st, traceBlocks, treeDepth, dFrame, host.sc, ps, &wb.heads[0], &wb.counts[2], w->acc + 8, tuneP, S ? S + 0 : nullptr);
     rt_stage_end(ctx, ST_TRACE_PRIMARY, 1, st);
 
     rt_stage_begin(ctx, ST_POST_PRIMARY, st);
@@ -899,7 +908,7 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
             qg.o = wb.giO; qg.d = wb.giD; qg.tm = wb.giL; qg.liveCount = &wb.counts[1]; qg.c0 = c0; qg.cap = wb.CH; qg.stride = wb.CH; qg.slots = (uint32_t)SPP;
             qg.outT = wb.giT; qg.outTri = wb.giTri; qg.outOcc = nullptr;
             rt_stage_begin(ctx, ST_TRACE_GI, st);
-            launch_trace<QueueSrc, false>(st, traceBlocks, treeDepth, dFrame, host.sc, qg, &wb.heads[(size_t)(1 + c * 3 + 1) * kHeadWords], &wb.counts[4], tune, S ? S + 32 : nullptr);
+            launch_trace<QueueSrc, false>(st, traceBlocks, treeDepth, dFrame, host.sc, qg, &wb.heads[(size_t)(1 + c * 3 + 1) * kHeadWords], &wb.counts[4], w->acc + 10, tune, S ? S + 32 : nullptr);
             rt_stage_end(ctx, ST_TRACE_GI, 1, st);
 
             rt_stage_begin(ctx, ST_GEN_GI, st);
@@ -912,11 +921,11 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
             qq.b.stride = wb.CH * (uint32_t)SPP; qq.b.slots = 6u;
             qq.b.outT = nullptr; qq.b.outTri = nullptr; qq.b.outOcc = wb.occ2;
             rt_stage_begin(ctx, ST_TRACE_SHADOW, st);
-            launch_trace<DualQueueSrc, true>(st, traceBlocks, treeDepth, dFrame, host.sc, qq, &wb.heads[(size_t)(1 + c * 3 + 0) * kHeadWords], &wb.counts[3], tune, S ? S + 16 : nullptr);
+            launch_trace<DualQueueSrc, true>(st, traceBlocks, treeDepth, dFrame, host.sc, qq, &wb.heads[(size_t)(1 + c * 3 + 0) * kHeadWords], &wb.counts[3], w->acc + 9, tune, S ? S + 16 : nullptr);
             rt_stage_end(ctx, ST_TRACE_SHADOW, 1, st);
         } else {
             rt_stage_begin(ctx, ST_TRACE_SHADOW, st);
-            launch_trace<QueueSrc, true>(st, traceBlocks, treeDepth, dFrame, host.sc, q1, &wb.heads[(size_t)(1 + c * 3 + 0) * kHeadWords], &wb.counts[3], tune, S ? S + 16 : nullptr);
+            launch_trace<QueueSrc, true>(st, traceBlocks, treeDepth, dFrame, host.sc, q1, &wb.heads[(size_t)(1 + c * 3 + 0) * kHeadWords], &wb.counts[3], w->acc + 9, tune, S ? S + 16 : nullptr);
             rt_stage_end(ctx, ST_TRACE_SHADOW, 1, st);
         }
         rt_stage_begin(ctx, ST_COMBINE, st);
@@ -933,11 +942,11 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
     return RT_OK;
 }
 
-int rt_wave_traced(RtWave *w, hipStream_t st, unsigned long long *out8, bool reset) {
-    for (int i = 0; i < 8; ++i) out8[i] = 0;
+int rt_wave_traced(RtWave *w, hipStream_t st, unsigned long long *out8, bool reset) {   // out8: 16 words, [8..11] = gather loads per trace stage
+    for (int i = 0; i < 16; ++i) out8[i] = 0;
     if (!w->acc) return RT_OK;
     W_TRY(hipStreamSynchronize(st));
-    W_TRY(hipMemcpy(out8, w->acc, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    W_TRY(hipMemcpy(out8, w->acc, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     if (w->stats) {
         unsigned long long v[64];
         W_TRY(hipMemcpy(v, w->stats, sizeof v, hipMemcpyDeviceToHost));
@@ -952,6 +961,6 @@ int rt_wave_traced(RtWave *w, hipStream_t st, unsigned long long *out8, bool res
         }
         if (reset) W_TRY(hipMemset(w->stats, 0, sizeof v));
     }
-    if (reset) W_TRY(hipMemset(w->acc, 0, 8 * sizeof(unsigned long long)));
+    if (reset) W_TRY(hipMemset(w->acc, 0, 16 * sizeof(unsigned long long)));
     return RT_OK;
 }
