@@ -8,4 +8,5 @@ us=[rt.frame_uniforms(p,cam,W,H,f,True,nodes.shape[0],tris.shape[0]) for f in ra
 for f in range(5): r.render_frame(us[f])
 r.synchronize(); t=time.perf_counter()
 for f in range(5,N+5): r.render_frame(us[f])
-r.synchronize(); print(round((time.perf_counter()-t)/N*1e3,3),"ms/frame")
+t_issue=time.perf_counter()-t
+r.synchronize(); print("host issue", round(t_issue/N*1e3,3), "ms/frame;", end=" "); print(round((time.perf_counter()-t)/N*1e3,3),"ms/frame")
