@@ -205,6 +205,20 @@ int rt_assemble_gathered(RtContext *ctx, int which, const void *gatheredDev, voi
 /* the context's HIP stream (hipStream_t) so a caller can order its own work after the frame */
 int rt_stream(RtContext *ctx, void **hipStream);
 
+/* Tile-parallel frame with a MOVING camera.  Reprojection (rt_taa.glsl:116-179) reads the previous frame at arbitrary
+ * pixels, i.e. in other ranks' tiles, so every rank needs the whole previous COLOR0.  After rt_render_frame(f) the host
+ * all-gathers the ranks' COLOR0 blocks (rt_local_target / rt_gather_block_bytes) into the buffer returned by
+ * rt_history_exchange_buffer -- worldSize blocks, rank-major, on rt_stream() -- and then calls rt_history_exchanged();
+ * frame f+1 may then be rendered with cameraMoved = 1 (without the exchange: RT_ERR_STATE).  Static-camera frames need
+ * no exchange: a pixel only reads its own history.  Both calls refer to the frame rendered last. */
+int rt_history_exchange_buffer(RtContext *ctx, void **devPtr, size_t *bytes);
+int rt_history_exchanged(RtContext *ctx);
+
+/* Present pass over a tile-parallel frame on the gathering rank: the four arguments are device arrays of worldSize gathered
+ * blocks each (as filled by the gather of COLOR / MOTION / GPOS / GNRM, rank-major, rt_gather_block_bytes per block). */
+int rt_present_gathered(RtContext *ctx, const RtPresentParams *p, const void *gatheredColor, const void *gatheredMotion,
+                        const void *gatheredGPos, const void *gatheredGNrm, uint8_t *dstRGBA8);
+
 int rt_get_counters(RtContext *ctx, RtCounters *out);   /* needs countWork; totals since rt_reset_counters */
 int rt_reset_counters(RtContext *ctx);
 

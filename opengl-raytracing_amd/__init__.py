@@ -164,6 +164,9 @@ SIGNATURES = {
     "rt_write_target": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "rt_make_present_params": (None, [C.POINTER(RtRenderParams), C.c_int, C.c_int, C.c_int, C.POINTER(RtPresentParams)]),
     "rt_present": (C.c_int, [C.c_void_p, C.POINTER(RtPresentParams), _U8P]),
+    "rt_history_exchange_buffer": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "rt_history_exchanged": (C.c_int, [C.c_void_p]),
+    "rt_present_gathered": (C.c_int, [C.c_void_p, C.POINTER(RtPresentParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _U8P]),
     "rt_local_target": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "rt_gather_block_bytes": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]),
     "rt_assemble_gathered": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
@@ -486,6 +489,22 @@ class Renderer:
         """Present pass with an explicit rt_present.frag uniform block."""
         out = np.zeros((self.height, self.width, 4), np.uint8)
         self._check(lib().rt_present(self._h, C.byref(pp), out.ctypes.data_as(_U8P)))
+        return out
+
+    def history_exchange_buffer(self):
+        """(device pointer, bytes) of the buffer the ranks' COLOR0 blocks of the last frame are all-gathered into (moving camera)."""
+        p, n = C.c_void_p(), C.c_size_t()
+        self._check(lib().rt_history_exchange_buffer(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def history_exchanged(self):
+        self._check(lib().rt_history_exchanged(self._h))
+
+    def present_gathered(self, pp: RtPresentParams, color_ptr, motion_ptr, gpos_ptr, gnrm_ptr) -> np.ndarray:
+        """Present pass on the gathering rank over four device arrays of gathered blocks -> [H, W, 4] uint8."""
+        out = np.zeros((self.height, self.width, 4), np.uint8)
+        self._check(lib().rt_present_gathered(self._h, C.byref(pp), C.c_void_p(color_ptr), C.c_void_p(motion_ptr), C.c_void_p(gpos_ptr),
+                                              C.c_void_p(gnrm_ptr), out.ctypes.data_as(_U8P)))
         return out
 
     def read_all(self):

@@ -35,6 +35,8 @@ struct RtContext {
     std::string err;
     // scene
     float4 *dWNodes = nullptr, *dW4 = nullptr, *dTris = nullptr;
+    void *dHistAll[RT_MAX_LANES] = {};      // tile-parallel + moving camera: every rank's COLOR0 block of the frame a lane rendered
+    bool histExchanged[RT_MAX_LANES] = {};
     uchar4 *dEnv = nullptr;
     int envSize = 0;
     int nNodes = 0, nTris = 0, nInner = 0, rootRef = 0, rootRef4 = 0, treeDepth = 0;
@@ -196,6 +198,7 @@ DevScene make_dev_scene(const RtContext *c) {
 
 void free_targets(RtContext *c) {
     for (int i = 0; i < RT_MAX_LANES; ++i) { if (c->dColor[i]) (void)hipFree(c->dColor[i]); c->dColor[i] = nullptr; }
+    for (int i = 0; i < RT_MAX_LANES; ++i) { if (c->dHistAll[i]) (void)hipFree(c->dHistAll[i]); c->dHistAll[i] = nullptr; c->histExchanged[i] = false; }
     if (c->dMotion) (void)hipFree(c->dMotion);
     if (c->dGPos) (void)hipFree(c->dGPos);
     if (c->dGNrm) (void)hipFree(c->dGNrm);
@@ -516,8 +519,11 @@ int rt_render_frame(RtContext *c, const RtUniforms *uIn) {
     if (fr.u.useBVH == 1 && fr.u.nodeCount > 0 && fr.u.triCount > 0 && (c->nNodes == 0 || fr.u.nodeCount > c->nNodes || fr.u.triCount > c->nTris))
         return fail(c, RT_ERR_STATE, "rt_render_frame: uniforms name %d nodes / %d tris, uploaded %d / %d", fr.u.nodeCount, fr.u.triCount, c->nNodes, c->nTris);
     if (fr.u.useEnvMap == 1 && !c->dEnv) return fail(c, RT_ERR_STATE, "rt_render_frame: uUseEnvMap without an environment");
-    if (fr.u.cameraMoved == 1 && c->g.world > 1)
-        return fail(c, RT_ERR_UNSUPPORTED, "rt_render_frame: moving-camera reprojection reads other ranks' history; needs the history all-gather (not in this build)");
+    const int prevLaneX = (c->writeIdx + c->nLanes - 1) % c->nLanes;
+    const bool needAll = fr.u.cameraMoved == 1 && c->g.world > 1 && fr.u.enableTAA == 1 && c->frameIndex > 0;
+    if (needAll && !(c->dHistAll[prevLaneX] && c->histExchanged[prevLaneX]))
+        return fail(c, RT_ERR_STATE, "rt_render_frame: cameraMoved on a tile-parallel context: reprojection reads other ranks' history -- all-gather the "
+                                     "previous frame's COLOR0 blocks into rt_history_exchange_buffer() and call rt_history_exchanged() first");
     fr.sc = make_dev_scene(c);
     if (!(fr.u.nodeCount > 0 && fr.u.triCount > 0)) fr.sc.hasBVH = 0;
     fr.g = c->g;
@@ -530,6 +536,9 @@ int rt_render_frame(RtContext *c, const RtUniforms *uIn) {
     Targets tg;
     tg.color = c->dColor[c->writeIdx];
     tg.prev = c->dColor[prevLane];
+    tg.prevAll = needAll ? (const uint2 *)c->dHistAll[prevLane] : nullptr;
+    tg.blockSlots = (int)c->nSlots;
+    c->histExchanged[lane] = false;   // this lane's exchange buffer belongs to the frame that is about to be rendered
     tg.motion = c->dMotion; tg.gpos = c->dGPos; tg.gnrm = c->dGNrm;
     const bool count = c->cfg.countWork != 0;
     int pipeline = c->cfg.pipeline;
@@ -618,7 +627,7 @@ int rt_write_target(RtContext *c, int which, const void *srcHost, int fmt) {
 int rt_present(RtContext *c, const RtPresentParams *p, uint8_t *dst) {
     if (!c || !p || !dst) return RT_ERR_INVALID;
     if (!c->sized) return fail(c, RT_ERR_STATE, "rt_present before rt_resize");
-    if (c->g.world > 1) return fail(c, RT_ERR_UNSUPPORTED, "rt_present: the 7x7 filter reads other ranks' tiles; present on the gathering rank needs all four targets gathered (not in this build)");
+    if (c->g.world > 1) return fail(c, RT_ERR_UNSUPPORTED, "rt_present: the 7x7 filter reads other ranks' tiles; gather the four targets and use rt_present_gathered");
     if ((int)p->resolution[0] != c->g.W || (int)p->resolution[1] != c->g.H) return fail(c, RT_ERR_INVALID, "rt_present: uResolution != framebuffer");
     (void)hipSetDevice(c->cfg.device);
     const size_t bytes = (size_t)c->g.W * c->g.H * 4;
@@ -630,6 +639,47 @@ int rt_present(RtContext *c, const RtPresentParams *p, uint8_t *dst) {
     rt_stage_end(c, 11, 1);
     HIP_TRY(c, hipMemcpyAsync(dst, c->dStaging, bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, sync_all(c));
+    return RT_OK;
+}
+
+int rt_present_gathered(RtContext *c, const RtPresentParams *p, const void *color, const void *motion, const void *gpos, const void *gnrm, uint8_t *dst) {
+    if (!c || !p || !color || !motion || !gpos || !gnrm || !dst) return RT_ERR_INVALID;
+    if (!c->sized) return fail(c, RT_ERR_STATE, "rt_present_gathered before rt_resize");
+    if ((int)p->resolution[0] != c->g.W || (int)p->resolution[1] != c->g.H) return fail(c, RT_ERR_INVALID, "rt_present_gathered: uResolution != framebuffer");
+    (void)hipSetDevice(c->cfg.device);
+    const size_t bytes = (size_t)c->g.W * c->g.H * 4;
+    HIP_TRY(c, sync_all(c));
+    int rc = ensure_staging(c, bytes);
+    if (rc != RT_OK) return rc;
+    rt_stage_begin(c, 11);
+    HIP_TRY(c, rtl::launch_present(c->stream, c->g, (const uint2 *)color, (const uint32_t *)motion, (const uint2 *)gpos, (const uint2 *)gnrm, *p,
+                                   (uint32_t *)c->dStaging, (int)c->nSlots));
+    rt_stage_end(c, 11, 1);
+    HIP_TRY(c, hipMemcpyAsync(dst, c->dStaging, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, sync_all(c));
+    return RT_OK;
+}
+
+int rt_history_exchange_buffer(RtContext *c, void **devPtr, size_t *bytes) {
+    if (!c || !devPtr || !bytes) return RT_ERR_INVALID;
+    if (!c->sized) return fail(c, RT_ERR_STATE, "rt_history_exchange_buffer before rt_resize");
+    (void)hipSetDevice(c->cfg.device);
+    const int lane = (c->writeIdx + c->nLanes - 1) % c->nLanes;   // the frame rendered last
+    const size_t n = (size_t)c->g.world * c->nSlots * 8;
+    if (!c->dHistAll[lane]) HIP_TRY(c, hipMalloc(&c->dHistAll[lane], n));
+    *devPtr = c->dHistAll[lane];
+    *bytes = n;
+    return RT_OK;
+}
+int rt_history_exchanged(RtContext *c) {
+    if (!c) return RT_ERR_INVALID;
+    if (!c->sized) return fail(c, RT_ERR_STATE, "rt_history_exchanged before rt_resize");
+    (void)hipSetDevice(c->cfg.device);
+    const int lane = (c->writeIdx + c->nLanes - 1) % c->nLanes;
+    if (!c->dHistAll[lane]) return fail(c, RT_ERR_STATE, "rt_history_exchanged without rt_history_exchange_buffer");
+    // the next frame's resolve waits on this event: it now also covers the all-gather the caller enqueued on rt_stream()
+    HIP_TRY(c, hipEventRecord(c->evDone[lane], c->lanes[lane]));
+    c->histExchanged[lane] = true;
     return RT_OK;
 }
 

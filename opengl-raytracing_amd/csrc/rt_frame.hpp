@@ -28,7 +28,9 @@ struct DevFrame {   // one copy in HBM, refreshed per frame; kernels read it thr
 
 struct Targets {
     uint2 *color;        // COLOR0 write ping  (RGBA16F: rgb + luma second moment), rt.frag:29
-    const uint2 *prev;   // COLOR0 read pong   (uPrevAccum)
+    const uint2 *prev;   // COLOR0 read pong   (uPrevAccum), this rank's tiles
+    const uint2 *prevAll;   // tile-parallel + moving camera: every rank's COLOR0 block of the previous frame, rank-major (or null)
+    int blockSlots;         // slots per rank block in prevAll
     uint32_t *motion;    // COLOR1 RG16F
     uint2 *gpos;         // COLOR2 RGBA16F
     uint2 *gnrm;         // COLOR3 RGBA16F
@@ -64,9 +66,20 @@ RT_DEV V4 unpack_half4(uint2 r) {
                f16_bits_to_f32((uint16_t)(r.y & 0xffffu)), f16_bits_to_f32((uint16_t)(r.y >> 16)));
 }
 
+// slot of pixel (x,y) in a rank-major array of gathered blocks (blockSlots slots per rank), whoever owns it
+RT_DEV int slot_in_gathered(const FrameGeom &g, int x, int y, int blockSlots) {
+    int tx = x >> 4, ty = y >> 4;
+    int t = ty * g.tilesX + tx;
+    int lx = x & 15, ly = y & 15;
+    int q = (lx >> 3) | ((ly >> 3) << 1);
+    return (t % g.world) * blockSlots + (t / g.world) * 256 + q * 64 + (ly & 7) * 8 + (lx & 7);
+}
+
 // History access for resolveTAA (rt_taa.glsl:87,128): NEAREST, CLAMP_TO_EDGE.
 struct HistoryTex {
     const uint2 *prev;
+    const uint2 *prevAll;
+    int blockSlots;
     const FrameGeom *g;
     int slot;
     RT_DEV V4 own() const { return unpack_half4(prev[slot]); }
@@ -74,8 +87,9 @@ struct HistoryTex {
         int x = (int)__builtin_floorf(u * (float)g->W), y = (int)__builtin_floorf(v * (float)g->H);
         x = min(max(x, 0), g->W - 1);
         y = min(max(y, 0), g->H - 1);
+        if (prevAll) return unpack_half4(prevAll[slot_in_gathered(*g, x, y, blockSlots)]);   // reprojection crosses tiles: exchanged history
         int s = slot_of_pixel(*g, x, y);
-        return unpack_half4(prev[s < 0 ? slot : s]);   // s < 0 only with world > 1, which the host rejects for moving cameras
+        return unpack_half4(prev[s < 0 ? slot : s]);   // s < 0 only with world > 1, where the host insists on the exchanged history
     }
 };
 
@@ -96,7 +110,7 @@ RT_DEV void flush_work(const Work &w, unsigned long long *counters) {
 struct RtWaveBuffers;   // rt_wave.hip
 namespace rtl {
 hipError_t launch_present(hipStream_t s, const rtd::FrameGeom &g, const uint2 *color, const uint32_t *motion, const uint2 *gpos,
-                          const uint2 *gnrm, const RtPresentParams &p, uint32_t *outRGBA8);
+                          const uint2 *gnrm, const RtPresentParams &p, uint32_t *outRGBA8, int gatheredBlockSlots = 0);
 hipError_t launch_mega(hipStream_t s, const rtd::DevFrame *frame, rtd::Targets tg, unsigned long long *counters, bool count,
                        int stackDepth, int nLocalTiles);
 }

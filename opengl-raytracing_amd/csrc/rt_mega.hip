@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void k_mega(const DevFrame *__restrict__ fr, T
         float uvx = ((float)px + 0.5f) / (float)g.W, uvy = ((float)py + 0.5f) / (float)g.H;   // rt_fullscreen.vert:44
         V2 taaMotion = (u.cameraMoved == 1) ? motionOut : mk2(0.0f, 0.0f);
         HistoryTex hist;
-        hist.prev = tg.prev; hist.g = &g; hist.slot = slot;
+        hist.prev = tg.prev; hist.prevAll = tg.prevAll; hist.blockSlots = tg.blockSlots; hist.g = &g; hist.slot = slot;
         V4 taa = resolveTAA(u, curr, uvx, uvy, taaMotion, u.frameIndex, hist);
         tg.color[slot] = pack_half4(taa);
         tg.motion[slot] = pack_half2(motionOut);

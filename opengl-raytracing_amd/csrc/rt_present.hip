@@ -15,13 +15,15 @@ struct PresentTex {
     const uint32_t *motion;
     const uint2 *gpos, *gnrm;
     FrameGeom g;
+    int blockSlots;   // > 0: the four targets are rank-major arrays of gathered blocks (tile-parallel frame on the gathering rank)
 };
 
-RT_DEV int texel_slot(const FrameGeom &g, float u, float v) {   // texture(sampler2D, uv) with NEAREST + CLAMP_TO_EDGE
+RT_DEV int texel_slot(const PresentTex &T, float u, float v) {   // texture(sampler2D, uv) with NEAREST + CLAMP_TO_EDGE
+    const FrameGeom &g = T.g;
     int x = (int)__builtin_floorf(u * (float)g.W), y = (int)__builtin_floorf(v * (float)g.H);
     x = min(max(x, 0), g.W - 1);
     y = min(max(y, 0), g.H - 1);
-    return slot_of_pixel(g, x, y);
+    return T.blockSlots > 0 ? slot_in_gathered(g, x, y, T.blockSlots) : slot_of_pixel(g, x, y);
 }
 RT_DEV V3 aces(V3 x, float exposure) {
     x = x * exposure;
@@ -48,7 +50,7 @@ __global__ __launch_bounds__(256) void k_present(PresentTex T, RtPresentParams P
     if (i >= T.g.W * T.g.H) return;
     const int px = i % T.g.W, py = i / T.g.W;
     const float u = (((float)px + 0.5f) + 0.5f) / (float)T.g.W, v = (((float)py + 0.5f) + 0.5f) / (float)T.g.H;   // rt_present.frag:233
-    const int sc = texel_slot(T.g, u, v);
+    const int sc = texel_slot(T, u, v);
     V3 rgb;
     if (P.showMotion == 1) {
         V2 m = unpack_half2(T.motion[sc]);
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(256) void k_present(PresentTex T, RtPresentParams P
                 for (int k = -3; k <= 3; ++k) {
                     float un = u + (float)k * texelX, vn = v + (float)j * texelY;
                     if (un < 0.0f || un > 1.0f || vn < 0.0f || vn > 1.0f) continue;
-                    const int sn = texel_slot(T.g, un, vn);
+                    const int sn = texel_slot(T, un, vn);
                     V4 s = unpack_half4(T.color[sn]);
                     V3 c = mk3(s.x, s.y, s.z);
                     V3 dc = c - cCenter;
@@ -111,9 +113,9 @@ __global__ __launch_bounds__(256) void k_present(PresentTex T, RtPresentParams P
 
 namespace rtl {
 hipError_t launch_present(hipStream_t s, const FrameGeom &g, const uint2 *color, const uint32_t *motion, const uint2 *gpos,
-                          const uint2 *gnrm, const RtPresentParams &p, uint32_t *outRGBA8) {
+                          const uint2 *gnrm, const RtPresentParams &p, uint32_t *outRGBA8, int gatheredBlockSlots) {
     PresentTex T;
-    T.color = color; T.motion = motion; T.gpos = gpos; T.gnrm = gnrm; T.g = g;
+    T.color = color; T.motion = motion; T.gpos = gpos; T.gnrm = gnrm; T.g = g; T.blockSlots = gatheredBlockSlots;
     const unsigned n = (unsigned)(g.W * g.H);
     hipLaunchKernelGGL(k_present, dim3((n + 255) / 256), dim3(256), 0, s, T, p, outRGBA8);
     return hipGetLastError();

@@ -27,8 +27,13 @@ def wrap_device_bytes(ptr, nbytes, device):
 
 
 class FrameGatherer:
-    def __init__(self, renderer, which=RT_TARGET_COLOR, group=None):
+    """exchange_history: also all-gather COLOR0 to EVERY rank after each frame (rt_history_exchange_buffer), which a moving
+    camera needs: reprojection reads the previous frame in other ranks' tiles.  Costs worldSize-1 more block copies per rank and
+    frame over xGMI; leave it off for static cameras (a pixel then only reads its own history)."""
+
+    def __init__(self, renderer, which=RT_TARGET_COLOR, group=None, exchange_history=False):
         self.ren, self.which, self.group = renderer, which, group
+        self.exchange_history = exchange_history
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.device = torch.device("cuda", torch.cuda.current_device())
@@ -62,7 +67,49 @@ class FrameGatherer:
                 self.gathered[0].copy_(loc, non_blocking=True)
             if self.rank == 0:
                 self.ren.assemble_gathered(self.which, self.gathered.data_ptr(), self.frame.data_ptr())
+            if self.exchange_history and self.world > 1:
+                col = loc if self.which == RT_TARGET_COLOR else self._local_of(RT_TARGET_COLOR)
+                ptr, nbytes = self.ren.history_exchange_buffer()
+                dst = self._wrapped.get(("hist", ptr))
+                if dst is None:
+                    dst = self._wrapped[("hist", ptr)] = wrap_device_bytes(ptr, nbytes, self.device)
+                dist.all_gather_into_tensor(dst, col, group=self.group)
+        if self.exchange_history and self.world > 1:
+            self.ren.history_exchanged()       # the next frame's temporal resolve now waits for the all-gather too
         return self.frame
+
+    def _local_of(self, which):
+        ptr, nbytes = self.ren.local_target(which)
+        t = self._wrapped.get(ptr)
+        if t is None:
+            t = self._wrapped[ptr] = wrap_device_bytes(ptr, nbytes, self.device)
+        return t
+
+    def gather_targets(self):
+        """Rank 0: all four targets of the last frame as gathered-block arrays (for rt_present_gathered); others: None."""
+        sp = self.ren.stream()
+        stream = self._streams.get(sp) or self._streams.setdefault(sp, torch.cuda.ExternalStream(sp, device=self.device))
+        outs = []
+        with torch.cuda.stream(stream):
+            for which in range(4):
+                loc = self._local_of(which)
+                blk = self.ren.gather_block_bytes(which)
+                g = torch.empty((self.world, blk), dtype=torch.uint8, device=self.device) if self.rank == 0 else None
+                if self.world > 1:
+                    dist.gather(loc, list(g.unbind(0)) if self.rank == 0 else None, dst=0, group=self.group)
+                else:
+                    g[0].copy_(loc, non_blocking=True)
+                outs.append(g)
+        return outs if self.rank == 0 else None
+
+    def present(self, present_params):
+        """Present pass of the last frame on rank 0 (RGBA8 [H, W, 4]); other ranks take part in the gathers and return None."""
+        g = self.gather_targets()
+        if self.rank != 0:
+            return None
+        self.ren.synchronize()
+        torch.cuda.synchronize()
+        return self.ren.present_gathered(present_params, *[t.data_ptr() for t in g])
 
     def frame_halfs(self):
         """Rank 0: the assembled frame as uint16 half bit patterns [H, W, C] on the host (synchronises)."""

@@ -68,3 +68,48 @@ def test_two_rank_tile_gather_equals_single_rank(tmp_path):
     d = np.load(GOLDEN / "bvh_closeup_48x32.npz")
     for f in range(frames.shape[0]):
         assert np.array_equal(frames[f], d[f"color{f}"]), f
+
+
+def _worker_moving(rank, world, port, out_path):
+    """Moving camera: reprojection reads the previous frame in other ranks' tiles, so every rank ALL-GATHERS the COLOR0 blocks
+    after each frame (what FrameGatherer(exchange_history=True) does with RCCL into rt_history_exchange_buffer)."""
+    for p in (str(ROOT), str(ROOT / "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import opengl_raytracing_amd as rt
+    from opengl_raytracing_amd import tiles
+    import oracle as orc
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    d = np.load(GOLDEN / "glsl_analytic_moving_48x36.npz")
+    H, W = d["color0"].shape[:2]
+    prev_full, frames = None, []
+    for f in range(d["uniforms"].shape[0]):
+        u = rt.RtUniforms.from_buffer_copy(d["uniforms"][f].tobytes())
+        mask = tiles.owner_mask(W, H, rank, world)
+        outs, _ = orc.render(u, None, None, d["env"], prev_full, mask=mask, nthreads=2)
+        local = torch.from_numpy(tiles.pack_local(outs[0], rank, world).view(np.uint8).copy())
+        blocks = [torch.empty_like(local) for _ in range(world)]
+        dist.all_gather(blocks, local)                                         # every rank gets every block
+        prev_full = tiles.assemble([b.numpy().view(np.uint16).reshape(-1, 4) for b in blocks], W, H)
+        frames.append(prev_full)
+    if rank == 1:                                                              # any rank holds the whole frame now
+        np.save(out_path, np.stack(frames))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_all_gather_for_a_moving_camera(tmp_path, orc):
+    import opengl_raytracing_amd as rt
+    out = tmp_path / "frames_moving.npy"
+    mp.spawn(_worker_moving, args=(2, _free_port(), str(out)), nprocs=2, join=True)
+    got = np.load(out)
+    d = np.load(GOLDEN / "glsl_analytic_moving_48x36.npz")
+    prev = None
+    for f in range(d["uniforms"].shape[0]):
+        u = rt.RtUniforms.from_buffer_copy(d["uniforms"][f].tobytes())
+        assert f == 0 or u.cameraMoved == 1
+        want, _ = orc.render(u, None, None, d["env"], prev)
+        assert np.array_equal(got[f], want[0]), f
+        prev = want[0]
