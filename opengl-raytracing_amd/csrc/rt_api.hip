@@ -498,6 +498,7 @@ int rt_reset_accum(RtContext *c) {
     HIP_TRY(c, sync_all(c));
     c->frameIndex = 0;
     c->writeIdx = 0;
+    for (int i = 0; i < RT_MAX_LANES; ++i) c->histExchanged[i] = false;
     for (int i = 0; i < c->nLanes; ++i) HIP_TRY(c, hipMemsetAsync(c->dColor[i], 0, c->nSlots * 8, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->dMotion, 0, c->nSlots * 4, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->dGPos, 0, c->nSlots * 8, c->stream));

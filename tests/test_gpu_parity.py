@@ -154,6 +154,28 @@ def test_bvh_scene_frames_wavefront(ren_wave, orc, cam_kind, spp):
         prev = want[0]
 
 
+@pytest.mark.parametrize("spp,W,H", [(16, 96, 64), (64, 48, 40)])
+def test_bvh_wavefront_high_spp(ren_wave, orc, spp, W, H):
+    """BASELINE configs 3-5 run at 16 and 64 spp: the ray queues hold 6*spp + aoSamples slots per hit, frames stay bit-exact."""
+    nodes, tris = scenes.bunny_bvh(3)
+    faces = scenes.tiny_env(8)
+    r = ren_wave
+    r.upload_bvh(nodes, tris)
+    r.upload_env(faces)
+    r.resize(W, H)
+    p = rt.default_render_params()
+    p.sppPerFrame = spp
+    cam = scenes.camera("closeup", aspect=W / H)
+    prev = None
+    for frame in range(2):
+        u = rt.frame_uniforms(p, cam, W, H, frame, True, nodes.shape[0], tris.shape[0])
+        r.render_frame(u)
+        want, cnt = orc.render(u, nodes, tris, faces, prev)
+        _assert_targets_equal(r.read_all(), want, orc, f"wavefront spp={spp} frame={frame}")
+        prev = want[0]
+    assert cnt.raysClosest >= cnt.hitPixels * spp
+
+
 @pytest.mark.parametrize("toggles", [dict(enableGI=0), dict(enableAO=0), dict(sunEnabled=0, pointLightEnabled=0),
                                      dict(enableEnvMap=0, skyEnabled=0), dict(enableTAA=0, enableJitter=0), dict(aoSamples=7)])
 def test_bvh_wavefront_feature_toggles(ren_wave, orc, toggles):
