@@ -4,6 +4,8 @@
 // cross (:281-304), then N x { mainLoop steps + renderRay } and the present pass, and writes the back buffer as PNG.
 //
 //   rt_cli --obj models/bunny.obj --env cubemaps/Sky_16.png --size 1920x1080 --spp 4 --frames 32 --bvh --out frame
+// Several --obj files are merged into one triangle soup before build_bvh (a multi-object scene, BASELINE config 5);
+// --dump-targets also writes the four render targets of the last frame as little-endian PFM (float, bottom row first).
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -19,7 +21,9 @@ static void die(RtContext *c, const char *what, int rc) {
 }
 
 int main(int argc, char **argv) {
-    std::string obj, env, out = "frame";
+    std::vector<std::string> objs;
+    std::string env, out = "frame";
+    bool dumpTargets = false;
     int W = 1920, H = 1080, frames = 1, device = 0, useBVH = 0, showMotion = 0;
     RtRenderParams params;
     rt_default_render_params(&params);
@@ -29,7 +33,8 @@ int main(int argc, char **argv) {
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         auto next = [&]() -> const char * { if (i + 1 >= argc) { std::fprintf(stderr, "rt_cli: %s needs a value\n", a.c_str()); std::exit(2); } return argv[++i]; };
-        if (a == "--obj") { obj = next(); useBVH = 1; }
+        if (a == "--obj") { objs.push_back(next()); useBVH = 1; }
+        else if (a == "--dump-targets") dumpTargets = true;
         else if (a == "--env") env = next();
         else if (a == "--out") out = next();
         else if (a == "--size") { if (std::sscanf(next(), "%dx%d", &W, &H) != 2) { std::fprintf(stderr, "rt_cli: --size WxH\n"); return 2; } }
@@ -49,7 +54,8 @@ int main(int argc, char **argv) {
         else if (a == "--fov") cam.fov = (float)std::atof(next());
         else if (a == "--aspect") { cam.aspect = (float)std::atof(next()); aspectSet = true; }
         else { std::fprintf(stderr, "usage: rt_cli [--obj f.obj] [--env cross.png] [--size WxH] [--spp n] [--frames n] [--bvh|--analytic] [--motion]\n"
-                                    "              [--cam x,y,z,yaw,pitch] [--fov deg] [--aspect a] [--exposure e] [--no-gi --no-ao --no-taa --no-svgf --no-env] [--out prefix]\n"); return a == "--help" ? 0 : 2; }
+                                    "              [--cam x,y,z,yaw,pitch] [--fov deg] [--aspect a] [--exposure e] [--no-gi --no-ao --no-taa --no-svgf --no-env] [--out prefix]\n"
+                                    "              (--obj may be repeated; --dump-targets writes prefix_{color,motion,gpos,gnrm}.pfm)\n"); return a == "--help" ? 0 : 2; }
     }
     if (!aspectSet) cam.aspect = (float)W / (float)H;
 
@@ -59,18 +65,25 @@ int main(int argc, char **argv) {
     int rc = rt_create(&cfg, &ctx);
     if (rc != RT_OK) die(nullptr, "rt_create", rc);
 
-    if (!obj.empty()) {
-        float *pos = nullptr; uint32_t *idx = nullptr; int nv = 0, ni = 0;
-        if ((rc = rt_load_obj(obj.c_str(), &pos, &nv, &idx, &ni)) != RT_OK) die(ctx, "rt_load_obj", rc);
+    if (!objs.empty()) {
         float M[16];
         rt_default_bvh_transform(M);                                  // include/app/state.h:26-31
-        std::vector<float> tris9((size_t)(ni / 3) * 9);
-        const int nt = rt_gather_triangles(pos, idx, ni, M, tris9.data());
+        std::vector<float> tris9;
+        for (const std::string &obj : objs) {
+            float *pos = nullptr; uint32_t *idx = nullptr; int nv = 0, ni = 0;
+            if ((rc = rt_load_obj(obj.c_str(), &pos, &nv, &idx, &ni)) != RT_OK) die(ctx, "rt_load_obj", rc);
+            const size_t at = tris9.size();
+            tris9.resize(at + (size_t)(ni / 3) * 9);
+            const int nt = rt_gather_triangles(pos, idx, ni, M, tris9.data() + at);
+            tris9.resize(at + (size_t)nt * 9);
+            std::printf("[OBJ] %s: %d vertices, %d triangles\n", obj.c_str(), nv, nt);
+            rt_free(pos); rt_free(idx);
+        }
+        const int nt = (int)(tris9.size() / 9);
         std::vector<float> nodes12((size_t)nt * 24 + 12), tris12((size_t)nt * 12 + 12);
         const int nn = rt_build_bvh(tris9.data(), nt, nodes12.data(), tris12.data());
         if ((rc = rt_upload_bvh(ctx, nodes12.data(), nn, tris12.data(), nt)) != RT_OK) die(ctx, "rt_upload_bvh", rc);
-        std::printf("[BVH] %s: %d vertices, %d triangles, %d nodes\n", obj.c_str(), nv, nt, nn);
-        rt_free(pos); rt_free(idx);
+        std::printf("[BVH] %d triangles, %d nodes\n", nt, nn);
     }
     if (!env.empty()) {
         uint8_t *px = nullptr; int w = 0, h = 0, ch = 0;
@@ -98,6 +111,25 @@ int main(int argc, char **argv) {
     const std::string png = out + ".png";
     if ((rc = rt_save_png(png.c_str(), rgba.data(), W, H, 4, /*flipY=*/1)) != RT_OK) die(ctx, "rt_save_png", rc);
     std::printf("[PRESENT] wrote %s\n", png.c_str());
+    if (dumpTargets) {
+        static const char *names[4] = {"color", "motion", "gpos", "gnrm"};
+        static const int chans[4] = {4, 2, 4, 4};
+        for (int t = 0; t < 4; ++t) {
+            std::vector<float> img((size_t)W * H * chans[t]);
+            if ((rc = rt_read_target(ctx, t, img.data(), RT_FORMAT_F32)) != RT_OK) die(ctx, "rt_read_target", rc);
+            // PFM holds 1 or 3 channels: RGB of COLOR0 / GPOS / GNRM, and motion as (x, y, 0)
+            std::vector<float> rgb((size_t)W * H * 3, 0.0f);
+            for (size_t i = 0; i < (size_t)W * H; ++i)
+                for (int c = 0; c < 3 && c < chans[t]; ++c) rgb[i * 3 + c] = img[i * chans[t] + c];
+            const std::string f = out + "_" + names[t] + ".pfm";
+            FILE *fp = std::fopen(f.c_str(), "wb");
+            if (!fp) { std::fprintf(stderr, "rt_cli: cannot write %s\n", f.c_str()); return 1; }
+            std::fprintf(fp, "PF\n%d %d\n-1.0\n", W, H);            // negative scale = little endian; rows bottom to top = our row order
+            std::fwrite(rgb.data(), sizeof(float), rgb.size(), fp);
+            std::fclose(fp);
+            std::printf("[DUMP] wrote %s\n", f.c_str());
+        }
+    }
     rt_destroy(ctx);
     return 0;
 }

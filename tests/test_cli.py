@@ -63,3 +63,44 @@ def test_cli_renders_the_same_frames_as_the_python_harness(tmp_path):
                 r.render_ray(p, c, use_bvh=(mode == "bvh"))
             want = r.present(p)[::-1]          # PNG rows are top-down
         assert np.array_equal(got, want), mode
+
+
+@pytest.mark.gpu
+def test_cli_merges_several_obj_files_and_dumps_the_targets(tmp_path):
+    """several .obj files -> one triangle soup -> build_bvh; --dump-targets writes the four targets as PFM."""
+    W, H = 96, 64
+    va, fa = rt.meshgen.bunny_standin(2)
+    vb, fb = rt.meshgen.bunny_standin(1)
+    vb = vb * 0.5 + np.array([0.6, 0.3, 0.0], np.float32)
+    rt.meshgen.write_obj(tmp_path / "a.obj", va, fa)
+    rt.meshgen.write_obj(tmp_path / "b.obj", vb, fb)
+    cam = "-2,1.5,1.0,-90,0"
+    args = [str(CLI), "--obj", str(tmp_path / "a.obj"), "--obj", str(tmp_path / "b.obj"), "--no-env", "--size", f"{W}x{H}", "--spp", "2",
+            "--frames", "2", "--cam", cam, "--dump-targets", "--out", str(tmp_path / "two")]
+    out = subprocess.run(args, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert f"[BVH] {(fa.size + fb.size) // 3} triangles" in out.stdout, out.stdout
+
+    def read_pfm(path):
+        with open(path, "rb") as f:
+            assert f.readline().strip() == b"PF"
+            w, h = map(int, f.readline().split())
+            assert float(f.readline()) < 0                      # little endian
+            return np.frombuffer(f.read(), "<f4").reshape(h, w, 3)
+
+    # the same scene through the Python harness
+    p = rt.default_render_params()
+    p.sppPerFrame = 2
+    p.enableEnvMap = 0
+    c = scenes.camera("closeup", aspect=W / H)
+    tris9 = np.concatenate([rt.gather_triangles(*rt.load_obj(tmp_path / "a.obj")), rt.gather_triangles(*rt.load_obj(tmp_path / "b.obj"))])
+    nodes, tris = rt.build_bvh(tris9)
+    with rt.Renderer() as r:
+        r.upload_bvh(nodes, tris)
+        r.resize(W, H)
+        for _ in range(2):
+            r.render_ray(p, c, use_bvh=True)
+        for which, name, ch in ((rt.RT_TARGET_COLOR, "color", 3), (rt.RT_TARGET_MOTION, "motion", 2), (rt.RT_TARGET_GPOS, "gpos", 3), (rt.RT_TARGET_GNRM, "gnrm", 3)):
+            want = r.read_target(which, rt.RT_FORMAT_F32)
+            got = read_pfm(tmp_path / f"two_{name}.pfm")
+            assert np.array_equal(got[:, :, :ch], want[:, :, :ch]), name
