@@ -945,7 +945,7 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
     return RT_OK;
 }
 
-int rt_wave_traced(RtWave *w, hipStream_t st, unsigned long long *out8, bool reset) {   // out8: 16 words, [8..11] = gather loads per trace stage
+int rt_wave_traced(RtWave *w, hipStream_t st, unsigned long long *out8, bool reset) {   // 16 words, see rt_wave.hpp
     for (int i = 0; i < 16; ++i) out8[i] = 0;
     if (!w->acc) return RT_OK;
     W_TRY(hipStreamSynchronize(st));

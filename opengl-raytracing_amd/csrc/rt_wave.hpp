@@ -15,9 +15,10 @@ const char *rt_wave_error(const RtWave *w);
 int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t stream, const rtd::DevFrame *dFrame, const rtd::DevFrame &host,
                    rtd::Targets tg, unsigned long long *counters, bool count, int treeDepth, hipEvent_t evPrevDone);
 
-// traced-ray tallies accumulated since the last reset: [0] candidate pixels [1] hit pixels [2] primary [3] shadow+AO
-// [4] bounce [5] bounce-shadow rays actually traversed, [6] frames
-int rt_wave_traced(RtWave *w, hipStream_t stream, unsigned long long *out8, bool reset);
+// tallies accumulated since the last reset, 16 words: [0] candidate pixels [1] hit pixels [2] primary [3] shadow+AO
+// [4] bounce [5] bounce-shadow rays actually traversed, [6] frames, [8..10] 16-byte gather loads issued by the primary /
+// any-hit / bounce traversal launches
+int rt_wave_traced(RtWave *w, hipStream_t stream, unsigned long long *out16, bool reset);
 
 // stage timing hooks (rt_api.hip); stage ids index rt_stage_name()
 void rt_stage_begin(RtContext *c, int stage, hipStream_t on = nullptr);   // on == nullptr: the context's stream
