@@ -1,0 +1,109 @@
+"""Randomised parity sweep: random meshes, cameras (inside / outside / grazing), toggles, spp, frame sizes (ragged tiles),
+moving and static cameras -- every frame of both pipelines must equal the oracle bit for bit.  Seeds are fixed; set
+RT_FUZZ_CASES to run more cases than the default dozen."""
+import os
+
+import numpy as np
+import pytest
+
+import opengl_raytracing_amd as rt
+import scenes
+
+pytestmark = pytest.mark.gpu
+CASES = int(os.environ.get("RT_FUZZ_CASES", "12"))
+
+
+def _case(seed):
+    rng = np.random.default_rng(1000 + seed)
+    subdiv = int(rng.integers(0, 4))
+    v, f = rt.meshgen.bunny_standin(subdiv, seed=int(rng.integers(1 << 30)))
+    v = v * rng.uniform(0.3, 2.0) + rng.normal(0, 0.3, 3).astype(np.float32)
+    nodes, tris = rt.build_bvh(rt.gather_triangles(v, f))
+    W, H = int(rng.integers(17, 90)), int(rng.integers(17, 70))
+    p = rt.default_render_params()
+    p.sppPerFrame = int(rng.choice([1, 1, 2, 3, 4, 5]))
+    for name in ("enableGI", "enableAO", "enableTAA", "enableJitter", "sunEnabled", "skyEnabled", "pointLightEnabled", "enableEnvMap"):
+        setattr(p, name, int(rng.random() < 0.75))
+    p.aoSamples = int(rng.integers(1, 7))
+    p.aoRadius = float(rng.uniform(0.05, 1.5))
+    p.sunYaw, p.sunPitch = float(rng.uniform(-180, 180)), float(rng.uniform(-80, 80))
+    p.pointLightPos[0], p.pointLightPos[1], p.pointLightPos[2] = [float(x) for x in rng.normal(0, 2.0, 3)]
+    cams = []
+    base = scenes.camera("closeup", aspect=W / H)
+    centre = v.mean(0)
+    kind = rng.integers(0, 4)
+    for k in range(3):
+        c = scenes.camera("closeup", aspect=W / H)
+        if kind == 0:      # orbiting outside, looking roughly at the mesh
+            c.pos[0], c.pos[1], c.pos[2] = [float(x) for x in centre + rng.normal(0, 1, 3) * 2.5]
+        elif kind == 1:    # inside / very close
+            c.pos[0], c.pos[1], c.pos[2] = [float(x) for x in centre + rng.normal(0, 0.2, 3)]
+        else:              # default-ish
+            c.pos[0], c.pos[1], c.pos[2] = base.pos[0] + float(rng.normal(0, 0.3)), base.pos[1] + float(rng.normal(0, 0.3)), base.pos[2] + float(rng.normal(0, 0.3))
+        c.yaw, c.pitch = float(rng.uniform(-180, 180)) if kind < 2 else base.yaw + float(rng.normal(0, 10)), float(rng.uniform(-60, 60)) if kind < 2 else float(rng.normal(0, 10))
+        c.fov = float(rng.uniform(30, 100))
+        cams.append(c)
+    moving = bool(rng.random() < 0.5)
+    faces = scenes.tiny_env(int(rng.choice([1, 2, 5, 8])), seed=int(rng.integers(100))) if p.enableEnvMap else None
+    return nodes, tris, faces, p, cams, moving, W, H
+
+
+@pytest.mark.parametrize("seed", range(CASES))
+def test_random_scene_matches_the_oracle_on_both_pipelines(orc, seed):
+    nodes, tris, faces, p, cams, moving, W, H = _case(seed)
+    for pipeline in (rt.RT_PIPELINE_WAVEFRONT, rt.RT_PIPELINE_MEGAKERNEL):
+        with rt.Renderer(pipeline=pipeline) as r:
+            r.upload_bvh(nodes, tris)
+            r.upload_env(faces)
+            r.resize(W, H)
+            prev, prev_vp = None, None
+            for frame in range(3):
+                cam = cams[frame] if moving else cams[0]
+                u = rt.frame_uniforms(p, cam, W, H, frame, True, nodes.shape[0], tris.shape[0], prev_vp=prev_vp, env_loaded=faces is not None)
+                prev_vp = rt.mat4_mul(rt.camera_proj(cam), rt.camera_view(cam))
+                r.render_frame(u)
+                want, _ = orc.render(u, nodes, tris, faces, prev)
+                got = r.read_all()
+                for g, w_, name in zip(got, want, ("color", "motion", "gpos", "gnrm")):
+                    assert np.array_equal(g, w_), (seed, pipeline, frame, name, int(np.sum(g != w_)))
+                prev = want[0]
+
+
+@pytest.mark.parametrize("seed", range(CASES))
+def test_random_analytic_scene_matches_the_oracle(orc, seed):
+    """The analytic scene (plane + spheres, glass / mirror / point-light sphere): random cameras, materials, lights, toggles."""
+    rng = np.random.default_rng(5000 + seed)
+    W, H = int(rng.integers(17, 80)), int(rng.integers(17, 60))
+    p = rt.default_render_params()
+    p.sppPerFrame = int(rng.choice([1, 2, 3]))
+    for name in ("enableGI", "enableAO", "enableTAA", "enableJitter", "sunEnabled", "skyEnabled", "pointLightEnabled", "enableEnvMap",
+                 "matGlassEnabled", "matMirrorEnabled"):
+        setattr(p, name, int(rng.random() < 0.75))
+    p.matGlassIOR = float(rng.uniform(1.0, 2.2))
+    p.matGlassDistortion = float(rng.uniform(0.0, 0.5))
+    p.matMirrorGloss = float(rng.uniform(0.0, 1.0))
+    p.matAlbedoGloss = float(rng.uniform(1.0, 128.0))
+    p.matAlbedoSpecStrength = float(rng.uniform(0.0, 1.0))
+    p.pointLightPos[0], p.pointLightPos[1], p.pointLightPos[2] = float(rng.normal(0, 2)), float(rng.uniform(0.2, 4)), float(rng.normal(0, 2))
+    p.aoSamples = int(rng.integers(1, 6))
+    faces = scenes.tiny_env(int(rng.choice([1, 3, 8])), seed=int(rng.integers(100))) if p.enableEnvMap else None
+    cams = []
+    for k in range(3):
+        c = scenes.camera("default", aspect=W / H)
+        c.pos[0] += float(rng.normal(0, 1.5)); c.pos[1] = float(rng.uniform(0.1, 5.0)); c.pos[2] += float(rng.normal(0, 1.5))
+        c.yaw += float(rng.normal(0, 40)); c.pitch += float(rng.normal(0, 25)); c.fov = float(rng.uniform(25, 110))
+        cams.append(c)
+    moving = bool(rng.random() < 0.5)
+    with rt.Renderer() as r:
+        r.upload_env(faces)
+        r.resize(W, H)
+        prev, prev_vp = None, None
+        for frame in range(3):
+            cam = cams[frame] if moving else cams[0]
+            u = rt.frame_uniforms(p, cam, W, H, frame, False, prev_vp=prev_vp, env_loaded=faces is not None)
+            prev_vp = rt.mat4_mul(rt.camera_proj(cam), rt.camera_view(cam))
+            r.render_frame(u)
+            want, _ = orc.render(u, None, None, faces, prev)
+            for g, w_, name in zip(r.read_all(), want, ("color", "motion", "gpos", "gnrm")):
+                assert np.array_equal(g, w_), (seed, frame, name, int(np.sum(g != w_)))
+            prev = want[0]
