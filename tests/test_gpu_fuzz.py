@@ -107,3 +107,50 @@ def test_random_analytic_scene_matches_the_oracle(orc, seed):
             for g, w_, name in zip(r.read_all(), want, ("color", "motion", "gpos", "gnrm")):
                 assert np.array_equal(g, w_), (seed, frame, name, int(np.sum(g != w_)))
             prev = want[0]
+
+
+@pytest.mark.parametrize("seed", range(max(CASES // 3, 4)))
+def test_random_tile_parallel_frames_equal_the_single_rank_frames(seed):
+    """Random world sizes (2..8 ranks emulated on one GPU), ragged frame sizes, static or moving camera (with the history exchange):
+    the assembled COLOR0 and the gathered present must equal the single-context results bit for bit."""
+    import torch
+    from opengl_raytracing_amd.dist_gather import wrap_device_bytes
+    from test_gpu_multirank import _gather_blocks
+    nodes, tris, faces, p, cams, moving, W, H = _case(7000 + seed)
+    rng = np.random.default_rng(9000 + seed)
+    world = int(rng.integers(2, 9))
+    W, H = W + 40, H + 30
+    for c in cams:
+        c.aspect = W / H
+    with rt.Renderer() as single:
+        single.upload_bvh(nodes, tris); single.upload_env(faces); single.resize(W, H)
+        ranks = [rt.Renderer(rank=r, world_size=world) for r in range(world)]
+        try:
+            for r in ranks:
+                r.upload_bvh(nodes, tris); r.upload_env(faces); r.resize(W, H)
+            prev_vp = None
+            for frame in range(3):
+                cam = cams[frame] if moving else cams[0]
+                u = rt.frame_uniforms(p, cam, W, H, frame, True, nodes.shape[0], tris.shape[0], prev_vp=prev_vp, env_loaded=faces is not None)
+                prev_vp = rt.mat4_mul(rt.camera_proj(cam), rt.camera_view(cam))
+                single.render_frame(u)
+                for r in ranks:
+                    r.render_frame(u)
+                allc = _gather_blocks(ranks, rt.RT_TARGET_COLOR)
+                if moving:
+                    for r in ranks:
+                        ptr, n = r.history_exchange_buffer()
+                        wrap_device_bytes(ptr, n, torch.device("cuda", 0)).copy_(allc.reshape(-1))
+                        torch.cuda.synchronize()
+                        r.history_exchanged()
+                out = torch.empty((H, W, 8), dtype=torch.uint8, device="cuda")
+                ranks[0].assemble_gathered(rt.RT_TARGET_COLOR, allc.data_ptr(), out.data_ptr())
+                ranks[0].synchronize()
+                want = single.read_target(rt.RT_TARGET_COLOR)
+                assert np.array_equal(out.cpu().numpy().view("<u2").reshape(want.shape), want), (seed, world, frame, moving)
+            g = [_gather_blocks(ranks, which) for which in range(4)]
+            pp = rt.make_present_params(p, False, W, H)
+            assert np.array_equal(ranks[0].present_gathered(pp, *[t.data_ptr() for t in g]), single.present_with(pp)), (seed, world)
+        finally:
+            for r in ranks:
+                r.close()
