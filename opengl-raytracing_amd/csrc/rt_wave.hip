@@ -570,6 +570,9 @@ struct GenDirectTracer {   // records first-generation rays of (hit j, sample s)
     RT_DEV bool shadow(int, int k, V3 ro, V3 rd, float tMax, bool matters) {
         uint32_t a = (uint32_t)(wb.A + s * 6 + k) * wb.CH + j;
         shadowMask |= 1u << k;
+        // sun (k = 4) and point-light (k = 5) rays start at hp + N*e / hp + L*e towards a fixed light: the same ray for every
+        // sample of the pixel (rt_lighting.glsl:114-214 never look at the seed) -- sample 0 traces it, the others reuse its answer
+        if (k >= 4 && s > 0) { wb.shT[a] = -1.0f; return false; }
         if (!matters) { wb.shT[a] = -1.0f; return false; }   // dead ray: its answer is multiplied by zero
         wb.shT[a] = fmaxr(tMax, 0.0f);
         wb.shO[a] = mkf4(ro, 0.0f);
@@ -627,7 +630,7 @@ struct CombineTracer {     // reads everything
     int s;
     RT_DEV bool shadow(int seg, int k, V3, V3, float, bool matters) {
         if (!matters) return false;
-        if (seg == SEG_DIRECT) return wb.occ1[(uint32_t)(wb.A + s * 6 + k) * wb.CH + j] != 0;
+        if (seg == SEG_DIRECT) return wb.occ1[(uint32_t)(wb.A + (k >= 4 ? 0 : s) * 6 + k) * wb.CH + j] != 0;   // sun / point: sample 0's ray
         return wb.occ2[(uint32_t)k * (wb.CH * (uint32_t)wb.SPP) + (uint32_t)wb.giPos[(uint32_t)s * wb.CH + j]] != 0;
     }
     RT_DEV int gi(V3 ro, V3 rd, V3 &hp, V3 &hn) {
