@@ -154,3 +154,51 @@ def test_random_tile_parallel_frames_equal_the_single_rank_frames(seed):
         finally:
             for r in ranks:
                 r.close()
+
+
+@pytest.mark.parametrize("W,H", [(1, 1), (16, 16), (15, 17), (33, 1), (1, 40), (257, 3)])
+def test_degenerate_frame_sizes(orc, W, H):
+    """One pixel, exactly one tile, ragged in both directions, single rows / columns -- BVH on both pipelines and the analytic scene."""
+    nodes, tris = scenes.bunny_bvh(2)
+    faces = scenes.tiny_env(4)
+    p = rt.default_render_params()
+    p.sppPerFrame = 2
+    cam = scenes.camera("closeup", aspect=W / H)
+    for use_bvh, pipeline in ((True, rt.RT_PIPELINE_WAVEFRONT), (True, rt.RT_PIPELINE_MEGAKERNEL), (False, rt.RT_PIPELINE_AUTO)):
+        with rt.Renderer(pipeline=pipeline) as r:
+            r.upload_bvh(nodes, tris)
+            r.upload_env(faces)
+            r.resize(W, H)
+            prev = None
+            for frame in range(2):
+                u = rt.frame_uniforms(p, cam, W, H, frame, use_bvh, nodes.shape[0], tris.shape[0])
+                r.render_frame(u)
+                want, _ = orc.render(u, nodes, tris, faces, prev)
+                for g, w_, name in zip(r.read_all(), want, ("color", "motion", "gpos", "gnrm")):
+                    assert np.array_equal(g, w_), (W, H, use_bvh, pipeline, frame, name)
+                prev = want[0]
+            pp = rt.make_present_params(p, False, W, H)
+            assert np.array_equal(r.present_with(pp), orc.present(pp, r.read_all()))
+
+
+def test_empty_and_single_triangle_bvh(orc):
+    """uUseBVH = 1 with no triangles (rt_bvh.glsl:194: traceBVH returns false) and with a one-leaf tree."""
+    W, H = 40, 24
+    p = rt.default_render_params()
+    cam = scenes.camera("closeup", aspect=W / H)
+    tri = np.array([[-2.6, 1.0, -0.5, -1.4, 1.1, 0.4, -2.0, 2.2, 0.0]], np.float32)
+    nodes1, tris1 = rt.build_bvh(tri)
+    for nodes, tris in ((np.zeros((0, 12), np.float32), np.zeros((0, 12), np.float32)), (nodes1, tris1)):
+        for pipeline in (rt.RT_PIPELINE_AUTO, rt.RT_PIPELINE_MEGAKERNEL):
+            with rt.Renderer(pipeline=pipeline) as r:
+                r.upload_bvh(nodes, tris)
+                r.resize(W, H)
+                prev = None
+                for frame in range(2):
+                    u = rt.frame_uniforms(p, cam, W, H, frame, True, nodes.shape[0], tris.shape[0], env_loaded=False)
+                    r.render_frame(u)
+                    want, cnt = orc.render(u, nodes if nodes.shape[0] else None, tris if tris.shape[0] else None, None, prev)
+                    for g, w_, name in zip(r.read_all(), want, ("color", "motion", "gpos", "gnrm")):
+                        assert np.array_equal(g, w_), (nodes.shape[0], pipeline, frame, name)
+                    prev = want[0]
+    assert cnt.hitPixels > 0          # the single triangle is in view
