@@ -34,7 +34,8 @@ struct RtContext {
     hipEvent_t evDone[RT_MAX_LANES] = {};   // the frame on lane i has written its targets
     std::string err;
     // scene
-    float4 *dWNodes = nullptr, *dW4 = nullptr, *dTris = nullptr;
+    float4 *dWNodes = nullptr, *dW4 = nullptr, *dTris = nullptr, *dWNodesW = nullptr, *dPairs = nullptr;
+    int rootRefW = 0;
     void *dHistAll[RT_MAX_LANES] = {};      // tile-parallel + moving camera: every rank's COLOR0 block of the frame a lane rendered
     bool histExchanged[RT_MAX_LANES] = {};
     uchar4 *dEnv = nullptr;
@@ -185,6 +186,9 @@ DevScene make_dev_scene(const RtContext *c) {
     DevScene s;
     s.wnodes = c->dWNodes;
     s.w4 = c->dW4;
+    s.wnodesW = c->dWNodesW;
+    s.pairs = c->dPairs;
+    s.rootRefW = c->rootRefW;
     s.tris = c->dTris;
     s.env = c->dEnv;
     s.envSize = c->envSize;
@@ -309,6 +313,8 @@ void rt_destroy(RtContext *c) {
     for (int i = 1; i < RT_MAX_LANES; ++i) if (c->lanes[i]) (void)hipStreamDestroy(c->lanes[i]);
     if (c->dWNodes) (void)hipFree(c->dWNodes);
     if (c->dW4) (void)hipFree(c->dW4);
+    if (c->dWNodesW) (void)hipFree(c->dWNodesW);
+    if (c->dPairs) (void)hipFree(c->dPairs);
     if (c->dTris) (void)hipFree(c->dTris);
     if (c->dEnv) (void)hipFree(c->dEnv);
     if (c->dCounters) (void)hipFree(c->dCounters);
@@ -326,8 +332,10 @@ int rt_upload_bvh(RtContext *c, const float *nodes12, int nNodes, const float *t
     HIP_TRY(c, sync_all(c));
     if (c->dWNodes) (void)hipFree(c->dWNodes);
     if (c->dW4) (void)hipFree(c->dW4);
+    if (c->dWNodesW) (void)hipFree(c->dWNodesW);
+    if (c->dPairs) (void)hipFree(c->dPairs);
     if (c->dTris) (void)hipFree(c->dTris);
-    c->dWNodes = c->dW4 = c->dTris = nullptr;
+    c->dWNodes = c->dW4 = c->dTris = c->dWNodesW = c->dPairs = nullptr;
     c->nNodes = c->nTris = c->nInner = 0;
     c->treeDepth = 0;
     if (nNodes == 0 || nTris == 0) return RT_OK;
@@ -355,6 +363,33 @@ int rt_upload_bvh(RtContext *c, const float *nodes12, int nNodes, const float *t
         const N &n = nd[(size_t)node];
         return (n.count > 0) ? -(((n.first << 3) | (n.count - 1)) + 1) : innerIdx[(size_t)node];
     };
+    // Triangle PAIR records for the wavefront pipeline's traversal kernels: what bounds them is the number of 16-byte gather
+    // loads per ray, and a 48-byte triangle record carries only 36 bytes of payload.  Two triangles of a leaf are
+    // packed into 80 bytes = 5 loads instead of 6: floats [0..8] = v0,e1,e2 of the first, [9..17] of the second, [18] = index of the
+    // first in the reference's triangle array (closest-hit results name triangles by it), [19] unused.  A leaf owns
+    // ceil(count/2) consecutive records; its reference in the wavefront node arrays addresses the first of them.
+    std::vector<float> pairs;
+    std::vector<int> pairRefOf((size_t)nNodes, 0);
+    for (int i = 0; i < nNodes; ++i) {
+        const N &n = nd[(size_t)i];
+        if (n.count <= 0) continue;
+        const size_t rec = pairs.size() / 20;
+        if (rec + 8 >= ((size_t)1 << 28)) return fail(c, RT_ERR_UNSUPPORTED, "rt_upload_bvh: pair records exceed the 2^28 leaf encoding");
+        pairRefOf[(size_t)i] = -((int)((rec << 3) | (size_t)(n.count - 1)) + 1);
+        for (int t = 0; t < n.count; t += 2) {
+            float r[20] = {0};
+            for (int h = 0; h < 2 && t + h < n.count; ++h) {
+                const float *q = tris12 + (size_t)(n.first + t + h) * 12;
+                const float nine[9] = {q[0], q[1], q[2], q[4], q[5], q[6], q[8], q[9], q[10]};
+                std::memcpy(&r[9 * h], nine, sizeof nine);
+            }
+            const uint32_t orig = (uint32_t)(n.first + t);
+            std::memcpy(&r[18], &orig, 4);
+            pairs.insert(pairs.end(), r, r + 20);
+        }
+    }
+    pairs.resize(pairs.size() + 8 * 20, 0.0f);   // groups are fetched without a bounds branch
+    auto refOfW = [&](int node) { return (nd[(size_t)node].count > 0) ? pairRefOf[(size_t)node] : innerIdx[(size_t)node]; };
     std::vector<float> wn((size_t)std::max(nInner, 1) * 16, 0.0f);
     for (int i = 0; i < nNodes; ++i) {
         if (innerIdx[(size_t)i] < 0) continue;
@@ -365,6 +400,14 @@ int rt_upload_bvh(RtContext *c, const float *nodes12, int nNodes, const float *t
         o[4] = L[4]; o[5] = L[5]; o[6] = L[6]; std::memcpy(&o[7], &rr, 4);
         o[8] = R[0]; o[9] = R[1]; o[10] = R[2];
         o[12] = R[4]; o[13] = R[5]; o[14] = R[6];
+    }
+    std::vector<float> wnW = wn;   // the same records with pair-record leaf references (wavefront closest-hit kernels)
+    for (int i = 0; i < nNodes; ++i) {
+        if (innerIdx[(size_t)i] < 0) continue;
+        float *o = &wnW[(size_t)innerIdx[(size_t)i] * 16];
+        int rl = refOfW(nd[(size_t)i].left), rr = refOfW(nd[(size_t)i].right);
+        std::memcpy(&o[3], &rl, 4);
+        std::memcpy(&o[7], &rr, 4);
     }
     // depth of the tree (iterative), bounds the traversal stack: one deferred sibling per level
     int depth = 0;
@@ -384,7 +427,7 @@ int rt_upload_bvh(RtContext *c, const float *nodes12, int nNodes, const float *t
     // intermediate node; by monotonicity of the slab arithmetic a grandchild that passes its own test also passes
     // its parent's, so the set of triangles tested -- and hence every any-hit answer -- is unchanged.
     std::vector<float> w4;
-    int rootRef4 = refOf(0);
+    int rootRef4 = refOfW(0);
     if (nd[0].count <= 0) {
         struct Job { int bin; size_t at; };   // fill node `at` (index into w4 / 32) from binary node `bin`
         std::vector<Job> jobs;
@@ -403,7 +446,7 @@ int rt_upload_bvh(RtContext *c, const float *nodes12, int nNodes, const float *t
                 int ref = RT_NO_CHILD;
                 if (i < nk) {
                     const float *b = nodes12 + (size_t)kids[i] * 12;
-                    if (nd[(size_t)kids[i]].count > 0) ref = refOf(kids[i]);
+                    if (nd[(size_t)kids[i]].count > 0) ref = refOfW(kids[i]);
                     else {
                         ref = (int)(w4.size() / 32);
                         w4.resize(w4.size() + 32, 0.0f);
@@ -428,6 +471,11 @@ int rt_upload_bvh(RtContext *c, const float *nodes12, int nNodes, const float *t
     HIP_TRY(c, hipMalloc(&c->dW4, w4.size() * sizeof(float)));
     HIP_TRY(c, hipMemcpy(c->dW4, w4.data(), w4.size() * sizeof(float), hipMemcpyHostToDevice));
     c->rootRef4 = rootRef4;
+    c->rootRefW = refOfW(0);
+    HIP_TRY(c, hipMalloc(&c->dWNodesW, wnW.size() * sizeof(float)));
+    HIP_TRY(c, hipMemcpy(c->dWNodesW, wnW.data(), wnW.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMalloc(&c->dPairs, pairs.size() * sizeof(float)));
+    HIP_TRY(c, hipMemcpy(c->dPairs, pairs.data(), pairs.size() * sizeof(float), hipMemcpyHostToDevice));
     // 8 triangles of zero padding: the traversal kernels load triangle records in groups without a bounds branch
     HIP_TRY(c, hipMalloc(&c->dTris, (size_t)(nTris + 8) * 12 * sizeof(float)));
     HIP_TRY(c, hipMemset(c->dTris, 0, (size_t)(nTris + 8) * 12 * sizeof(float)));

@@ -28,11 +28,14 @@ namespace rtd {
 struct DevScene {
     const float4 *wnodes;
     const float4 *w4;
+    const float4 *wnodesW;   // wnodes with pair-record leaf references (wavefront closest-hit kernels)
+    const float4 *pairs;     // 5 x float4 per PAIR of triangles of a leaf: [v0 e1 e2][v0 e1 e2][index of the first][-], see rt_upload_bvh
     const float4 *tris;
     const uchar4 *env;
     int envSize;
     int rootRef;
     int rootRef4;
+    int rootRefW;
     int hasBVH;
     float rootMin[3], rootMax[3];
 };

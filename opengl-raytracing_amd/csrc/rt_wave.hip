@@ -436,7 +436,7 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
                         triBest = -1;
                         sp = 0;
                         leaf = 0;
-                        ref = ANY ? sc.rootRef4 : sc.rootRef;
+                        ref = ANY ? sc.rootRef4 : sc.rootRefW;
                         if (ANY && ref < 0) { leaf = ref; ref = RT_NO_CHILD; }   // single-leaf tree
                         float tmin;
                         bool in = sc.hasBVH && !tune.skipTraversal && slab(ro, rdInv, ld3(sc.rootMin), ld3(sc.rootMax), tmin) && !(tmin > tBest);
@@ -524,25 +524,31 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
         if (active && leafNow < 0) {
             if (STATS) st_[1]++;
             int v = -leafNow - 1;
-            int first = v >> 3, count = (v & 7) + 1;
+            int first = v >> 3, count = (v & 7) + 1;   // first: pair record, count: triangles
             bool done = false;
-            // Triangle records of a leaf are contiguous: fetch them LEAFB at a time so that the ~0.4-0.8 us gather
-            // round trips of one group overlap (the array is padded, so no bounds branch); test in leaf order.
+            // Two triangles of a leaf share one 80-byte record (5 gather loads instead of 6).  Records of a leaf are contiguous:
+            // fetch LEAFB/2 of them at a time so that the gather round trips of one group overlap (the array is padded, so no
+            // bounds branch); test in leaf order.
+            constexpr int NP = LEAFB / 2;
             for (int i = 0; i < count && !done; i += LEAFB) {
-                const float4 *t = sc.tris + (size_t)(first + i) * 3;
-                gathers += 3u * LEAFB;
-                float4 rec[LEAFB][3];
+                const float4 *t = sc.tris + (size_t)(first + (i >> 1)) * 5;
+                gathers += 5u * NP;
+                float4 rec[NP][5];
 #pragma unroll
-                for (int k = 0; k < LEAFB; ++k) { rec[k][0] = t[k * 3 + 0]; rec[k][1] = t[k * 3 + 1]; rec[k][2] = t[k * 3 + 2]; }
+                for (int k = 0; k < NP; ++k) { rec[k][0] = t[k * 5 + 0]; rec[k][1] = t[k * 5 + 1]; rec[k][2] = t[k * 5 + 2]; rec[k][3] = t[k * 5 + 3]; rec[k][4] = t[k * 5 + 4]; }
 #pragma unroll
-                for (int k = 0; k < LEAFB; ++k) { pin(rec[k][0]); pin(rec[k][1]); pin(rec[k][2]); }
+                for (int k = 0; k < NP; ++k) { pin(rec[k][0]); pin(rec[k][1]); pin(rec[k][2]); pin(rec[k][3]); pin(rec[k][4]); }
 #pragma unroll
                 for (int k = 0; k < LEAFB; ++k) {
+                    const float4 &r0 = rec[k >> 1][0], &r1 = rec[k >> 1][1], &r2 = rec[k >> 1][2], &r3 = rec[k >> 1][3], &r4 = rec[k >> 1][4];
+                    const V3 v0 = (k & 1) ? mk3(r2.y, r2.z, r2.w) : mk3(r0.x, r0.y, r0.z);
+                    const V3 e1 = (k & 1) ? mk3(r3.x, r3.y, r3.z) : mk3(r0.w, r1.x, r1.y);
+                    const V3 e2 = (k & 1) ? mk3(r3.w, r4.x, r4.y) : mk3(r1.z, r1.w, r2.x);
                     float tt;
                     if (STATS && !done && i + k < count) st_[2]++;
-                    if (!done && i + k < count && tri_hit(ro, rd, f4xyz(rec[k][0]), f4xyz(rec[k][1]), f4xyz(rec[k][2]), eps, tBest, tt)) {
+                    if (!done && i + k < count && tri_hit(ro, rd, v0, e1, e2, eps, tBest, tt)) {
                         if (ANY) done = true;
-                        else { tBest = tt; triBest = first + i + k; }
+                        else { tBest = tt; triBest = (int)f2u(r4.z) + (k & 1); }
                     }
                 }
             }
@@ -797,11 +803,11 @@ void launch_trace(hipStream_t st, int cus, int depth, const DevFrame *fr, const 
     const int s0 = ANY ? 24 : 16, s1 = ANY ? 36 : 24, s2 = ANY ? 48 : 32;
     const int stack = need <= s0 ? s0 : (need <= s1 ? s1 : s2);
     const int perCU = std::max(1, std::min(8, (160 * 1024) / (256 * stack * (ANY ? 4 : 8))));
-    const float4 *nodes = ANY ? hs.w4 : hs.wnodes;
+    const float4 *nodes = ANY ? hs.w4 : hs.wnodesW;
     dim3 g((unsigned)(cus * perCU)), b(256);
-#define RT_LAUNCH_TRACE(ST, LB) do { if (stats) hipLaunchKernelGGL((k_trace<Src, ANY, ST, LB, true>), g, b, 0, st, fr, nodes, hs.tris, src, head, tally, gatherLoads, tune, stats); \
-        else hipLaunchKernelGGL((k_trace<Src, ANY, ST, LB, false>), g, b, 0, st, fr, nodes, hs.tris, src, head, tally, gatherLoads, tune, (unsigned long long *)nullptr); } while (0)
-#define RT_LAUNCH_TRACE_LB(ST) do { if (tune.leafb >= 4) RT_LAUNCH_TRACE(ST, 4); else if (tune.leafb >= 2) RT_LAUNCH_TRACE(ST, 2); else RT_LAUNCH_TRACE(ST, 1); } while (0)
+#define RT_LAUNCH_TRACE(ST, LB) do { if (stats) hipLaunchKernelGGL((k_trace<Src, ANY, ST, LB, true>), g, b, 0, st, fr, nodes, hs.pairs, src, head, tally, gatherLoads, tune, stats); \
+        else hipLaunchKernelGGL((k_trace<Src, ANY, ST, LB, false>), g, b, 0, st, fr, nodes, hs.pairs, src, head, tally, gatherLoads, tune, (unsigned long long *)nullptr); } while (0)
+#define RT_LAUNCH_TRACE_LB(ST) do { if (tune.leafb >= 4) RT_LAUNCH_TRACE(ST, 4); else RT_LAUNCH_TRACE(ST, 2); } while (0)
     if (stack == s0) RT_LAUNCH_TRACE_LB((ANY ? 24 : 16));
     else if (stack == s1) RT_LAUNCH_TRACE_LB((ANY ? 36 : 24));
     else RT_LAUNCH_TRACE_LB((ANY ? 48 : 32));
