@@ -423,7 +423,8 @@ int rt_upload_bvh(RtContext *c, const float *nodes12, int nNodes, const float *t
         }
     }
     // 4-wide nodes for any-hit rays: every binary inner node at an even level absorbs its inner children, so one
-    // 128-byte record holds up to four grandchild boxes.  A child box is only skipped (never tested) when it is an
+    // 128-byte record holds up to four grandchild boxes -- stored component-wise, so that the 28 payload floats take 7 of the
+    // record's 8 sixteen-byte pieces and a visit costs 7 gather loads.  A child box is only skipped (never tested) when it is an
     // intermediate node; by monotonicity of the slab arithmetic a grandchild that passes its own test also passes
     // its parent's, so the set of triangles tested -- and hence every any-hit answer -- is unchanged.
     std::vector<float> w4;
@@ -452,17 +453,17 @@ int rt_upload_bvh(RtContext *c, const float *nodes12, int nNodes, const float *t
                         w4.resize(w4.size() + 32, 0.0f);
                         jobs.push_back({kids[i], (size_t)ref});
                     }
-                    float *o = &w4[jb.at * 32 + (size_t)i * 8];
-                    o[0] = b[0]; o[1] = b[1]; o[2] = b[2];
-                    o[4] = b[4]; o[5] = b[5]; o[6] = b[6];
+                    float *o = &w4[jb.at * 32];     // SoA: [min.x x4][min.y x4][min.z x4][max.x x4][max.y x4][max.z x4][ref x4][-]
+                    o[0 + i] = b[0]; o[4 + i] = b[1]; o[8 + i] = b[2];
+                    o[12 + i] = b[4]; o[16 + i] = b[5]; o[20 + i] = b[6];
                 } else {
                     // absent child: NaN box -- (NaN - ro) * rdInv = NaN, v_min/v_max drop NaN operands, tmax = NaN, and
                     // "tmax >= tmin" is false, so the traversal kernel needs no child-present branch
-                    float *o = &w4[jb.at * 32 + (size_t)i * 8];
+                    float *o = &w4[jb.at * 32];
                     const float qnan = std::nanf("");
-                    o[0] = o[1] = o[2] = o[4] = o[5] = o[6] = qnan;
+                    o[0 + i] = o[4 + i] = o[8 + i] = o[12 + i] = o[16 + i] = o[20 + i] = qnan;
                 }
-                std::memcpy(&w4[jb.at * 32 + (size_t)i * 8 + 3], &ref, 4);
+                std::memcpy(&w4[jb.at * 32 + 24 + (size_t)i], &ref, 4);
             }
         }
     } else w4.resize(32, 0.0f);

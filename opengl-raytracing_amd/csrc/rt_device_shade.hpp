@@ -23,7 +23,8 @@ namespace rtd {
 //   child reference: >= 0 -> inner node index;  < 0 -> leaf, v = -ref-1, first = v >> 3, count = (v & 7) + 1
 //   env   : 6 faces of RGBA8 (GL face order), envSize^2 texels each
 //   w4    : 8 x float4 per 4-wide node (two binary levels collapsed; any-hit rays only, where visiting order is
-//           free): [min_i.xyz, ref_i] [max_i.xyz, -] for i = 0..3, ref == RT_NO_CHILD for an absent child
+//           free), component-wise: [min.x of children 0..3] [min.y] [min.z] [max.x] [max.y] [max.z] [ref 0..3] [-]: 7 loads;
+//           ref == RT_NO_CHILD (and a NaN box) for an absent child
 #define RT_NO_CHILD 0x7fffffff
 struct DevScene {
     const float4 *wnodes;

@@ -465,20 +465,21 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
             if (STATS && lane == 0) { st_[3]++; st_[4] += (unsigned long long)__popcll(sm); }
             if (searching) {
                 if (STATS) st_[0]++;
-                gathers += ANY ? 8u : 4u;
+                gathers += ANY ? 7u : 4u;
                 if constexpr (ANY) {
                     // 4-wide node: up to four grandchild boxes per 128-byte record, order irrelevant for any-hit
                     const float4 *nd = nodes + (size_t)ref * 8;
-                    float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3], q4 = nd[4], q5 = nd[5], q6 = nd[6], q7 = nd[7];
-                    pin(q0); pin(q1); pin(q2); pin(q3); pin(q4); pin(q5); pin(q6); pin(q7);
-                    int r0 = (int)f2u(q0.w), r1 = (int)f2u(q2.w), r2 = (int)f2u(q4.w), r3 = (int)f2u(q6.w);
+                    // component-wise: [min.x x4][min.y x4][min.z x4][max.x x4][max.y x4][max.z x4][ref x4] = 7 loads, 8th piece unused
+                    float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3], q4 = nd[4], q5 = nd[5], q6 = nd[6];
+                    pin(q0); pin(q1); pin(q2); pin(q3); pin(q4); pin(q5); pin(q6);
+                    int r0 = (int)f2u(q6.x), r1 = (int)f2u(q6.y), r2 = (int)f2u(q6.z), r3 = (int)f2u(q6.w);
                     float t0, t1, t2, t3;
-                    bool h0 = slab(ro, rdInv, f4xyz(q0), f4xyz(q1), t0) && t0 <= tBest;
-                    bool h1 = slab(ro, rdInv, f4xyz(q2), f4xyz(q3), t1) && t1 <= tBest;
-                    // absent children carry NaN boxes: with v_min/v_max NaN semantics their slab test is false, so all eight
+                    bool h0 = slab(ro, rdInv, mk3(q0.x, q1.x, q2.x), mk3(q3.x, q4.x, q5.x), t0) && t0 <= tBest;
+                    bool h1 = slab(ro, rdInv, mk3(q0.y, q1.y, q2.y), mk3(q3.y, q4.y, q5.y), t1) && t1 <= tBest;
+                    // absent children carry NaN boxes: with v_min/v_max NaN semantics their slab test is false, so all
                     // loads are issued up front and the four tests are branch-free (no dependent "is there a child" round trip)
-                    bool h2 = slab(ro, rdInv, f4xyz(q4), f4xyz(q5), t2) && t2 <= tBest;
-                    bool h3 = slab(ro, rdInv, f4xyz(q6), f4xyz(q7), t3) && t3 <= tBest;
+                    bool h2 = slab(ro, rdInv, mk3(q0.z, q1.z, q2.z), mk3(q3.z, q4.z, q5.z), t2) && t2 <= tBest;
+                    bool h3 = slab(ro, rdInv, mk3(q0.w, q1.w, q2.w), mk3(q3.w, q4.w, q5.w), t3) && t3 <= tBest;
                     // Any-hit order is free, so leaves are postponed: the first leaf met goes to `leaf`, the lane goes on with an
                     // inner child (or pops one), and leaves are tested in the leaf phase when (nearly) every lane holds one --
                     // both phases run with more lanes busy than when a lane stops at its first leaf.
