@@ -840,7 +840,7 @@ RtWave *rt_wave_create(int cus) {
     w->cus = cus > 0 ? cus : 256;
     if (const char *e = getenv("RT_QUEUE_BUDGET_MB")) w->budgetBytes = (size_t)atoll(e) << 20;
     if (const char *e = getenv("RT_REFILL_MIN")) w->tune.refillMin = std::max(1, std::min(64, atoi(e)));
-    if (const char *e = getenv("RT_CHUNK")) w->tune.chunk = std::max(8, std::min(1 << 20, atoi(e)));
+    if (const char *e = getenv("RT_CHUNK")) { int v = atoi(e); w->tune.chunk = v <= 0 ? 0 : std::max(8, std::min(1 << 20, v)); }   // 0 = from the queue size
     if (const char *e = getenv("RT_DEBUG_SKIP_TRAVERSAL")) w->tune.skipTraversal = atoi(e);
     if (const char *e = getenv("RT_LEAFB")) w->tune.leafb = atoi(e);
     if (const char *e = getenv("RT_MIN_SEARCH")) w->tune.minSearch = std::max(0, std::min(64, atoi(e)));
