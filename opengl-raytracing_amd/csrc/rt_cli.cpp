@@ -9,11 +9,82 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstddef>
 #include <cstring>
+#include <fstream>
+#include <sstream>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/rt_mi355.h"
+
+// ---- scene files --------------------------------------------------------------------------------------------------------
+// --scene file.json: one flat JSON object.  Keys are RenderParams' field names (include/render/RenderParams.h: the reference
+// has no scene file, its defaults are the schema) plus: "obj" (string or array of strings), "env", "size" [W, H], "frames",
+// "bvh" (bool), "motion" (bool), "out", "camera" {"pos": [x, y, z], "yaw", "pitch", "fov"}.  Later command-line flags win.
+namespace scenefile {
+struct Value { enum Kind { Num, Str, Bool, Arr, Obj } kind = Num; double num = 0; std::string str; std::vector<Value> arr; std::vector<std::pair<std::string, Value>> obj; };
+struct Parser {
+    const std::string &s; size_t i = 0; std::string err;
+    void ws() { while (i < s.size() && (s[i] == ' ' || s[i] == '\n' || s[i] == '\t' || s[i] == '\r')) ++i; }
+    bool fail(const char *m) { if (err.empty()) err = std::string(m) + " at byte " + std::to_string(i); return false; }
+    bool str(std::string &out) {
+        if (i >= s.size() || s[i] != '"') return fail("expected string");
+        for (++i; i < s.size() && s[i] != '"'; ++i) { if (s[i] == '\\' && i + 1 < s.size()) ++i; out.push_back(s[i]); }
+        if (i >= s.size()) return fail("unterminated string");
+        ++i; return true;
+    }
+    bool value(Value &v) {
+        ws();
+        if (i >= s.size()) return fail("unexpected end");
+        if (s[i] == '"') { v.kind = Value::Str; return str(v.str); }
+        if (s[i] == '[') {
+            v.kind = Value::Arr; ++i; ws();
+            if (i < s.size() && s[i] == ']') { ++i; return true; }
+            for (;;) { Value e; if (!value(e)) return false; v.arr.push_back(e); ws(); if (i < s.size() && s[i] == ',') { ++i; continue; } if (i < s.size() && s[i] == ']') { ++i; return true; } return fail("expected , or ]"); }
+        }
+        if (s[i] == '{') {
+            v.kind = Value::Obj; ++i; ws();
+            if (i < s.size() && s[i] == '}') { ++i; return true; }
+            for (;;) { ws(); std::string k; if (!str(k)) return false; ws(); if (i >= s.size() || s[i] != ':') return fail("expected :"); ++i; Value e; if (!value(e)) return false; v.obj.emplace_back(k, e);
+                       ws(); if (i < s.size() && s[i] == ',') { ++i; continue; } if (i < s.size() && s[i] == '}') { ++i; return true; } return fail("expected , or }"); }
+        }
+        if (!s.compare(i, 4, "true")) { v.kind = Value::Bool; v.num = 1; i += 4; return true; }
+        if (!s.compare(i, 5, "false")) { v.kind = Value::Bool; v.num = 0; i += 5; return true; }
+        char *end = nullptr; v.kind = Value::Num; v.num = std::strtod(s.c_str() + i, &end);
+        if (end == s.c_str() + i) return fail("expected a value");
+        i = (size_t)(end - s.c_str()); return true;
+    }
+};
+struct Field { const char *name; int kind; size_t off; int n; };   // kind 0 = int32 (numbers and booleans), 1 = float[n]
+#define RT_PI(f) {#f, 0, offsetof(RtRenderParams, f), 1}
+#define RT_PF(f) {#f, 1, offsetof(RtRenderParams, f), 1}
+#define RT_P3(f) {#f, 1, offsetof(RtRenderParams, f), 3}
+static const Field kFields[] = {
+    RT_PI(sppPerFrame), RT_PF(exposure), RT_P3(matAlbedoColor), RT_PF(matAlbedoSpecStrength), RT_PF(matAlbedoGloss), RT_PI(matGlassEnabled),
+    RT_P3(matGlassColor), RT_PF(matGlassIOR), RT_PF(matGlassDistortion), RT_PI(matMirrorEnabled), RT_P3(matMirrorColor), RT_PF(matMirrorGloss),
+    RT_PI(enableJitter), RT_PF(jitterStillScale), RT_PF(jitterMovingScale), RT_PI(enableGI), RT_PF(giScaleAnalytic), RT_PF(giScaleBVH),
+    RT_PI(enableEnvMap), RT_PF(envMapIntensity), RT_PI(sunEnabled), RT_P3(sunColor), RT_PF(sunIntensity), RT_PF(sunYaw), RT_PF(sunPitch),
+    RT_PI(skyEnabled), RT_P3(skyColor), RT_PF(skyIntensity), RT_PF(skyYaw), RT_PF(skyPitch), RT_PI(pointLightEnabled), RT_P3(pointLightColor),
+    RT_PF(pointLightIntensity), RT_P3(pointLightPos), RT_PI(pointLightOrbitEnabled), RT_PF(pointLightOrbitRadius), RT_PF(pointLightOrbitSpeed),
+    RT_PF(pointLightYaw), RT_PF(pointLightPitch), RT_PI(enableAO), RT_PI(aoSamples), RT_PF(aoRadius), RT_PF(aoBias), RT_PF(aoMin), RT_PI(enableTAA),
+    RT_PF(taaStillThresh), RT_PF(taaHardMovingThresh), RT_PF(taaHistoryMinWeight), RT_PF(taaHistoryAvgWeight), RT_PF(taaHistoryMaxWeight),
+    RT_PF(taaHistoryBoxSize), RT_PI(enableSVGF), RT_PF(svgfVarMax), RT_PF(svgfKVar), RT_PF(svgfKColor), RT_PF(svgfKVarMotion),
+    RT_PF(svgfKColorMotion), RT_PF(svgfStrength), RT_PF(motionScale)};
+static bool set_param(RtRenderParams &p, const std::string &key, const Value &v) {
+    for (const Field &f : kFields) {
+        if (key != f.name) continue;
+        char *base = reinterpret_cast<char *>(&p) + f.off;
+        if (f.kind == 0) { if (v.kind != Value::Num && v.kind != Value::Bool) return false; *reinterpret_cast<int32_t *>(base) = (int32_t)v.num; return true; }
+        if (f.n == 1) { if (v.kind != Value::Num) return false; *reinterpret_cast<float *>(base) = (float)v.num; return true; }
+        if (v.kind != Value::Arr || (int)v.arr.size() != f.n) return false;
+        for (int k = 0; k < f.n; ++k) { if (v.arr[(size_t)k].kind != Value::Num) return false; reinterpret_cast<float *>(base)[k] = (float)v.arr[(size_t)k].num; }
+        return true;
+    }
+    return false;
+}
+}  // namespace scenefile
 
 static void die(RtContext *c, const char *what, int rc) {
     std::fprintf(stderr, "rt_cli: %s failed (%d): %s\n", what, rc, rt_last_error(c));
@@ -33,7 +104,39 @@ int main(int argc, char **argv) {
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         auto next = [&]() -> const char * { if (i + 1 >= argc) { std::fprintf(stderr, "rt_cli: %s needs a value\n", a.c_str()); std::exit(2); } return argv[++i]; };
-        if (a == "--obj") { objs.push_back(next()); useBVH = 1; }
+        if (a == "--scene") {
+            std::ifstream in(next());
+            if (!in) { std::fprintf(stderr, "rt_cli: cannot read scene file %s\n", argv[i]); return 2; }
+            std::stringstream ss; ss << in.rdbuf();
+            const std::string text = ss.str();
+            scenefile::Parser ps{text};
+            scenefile::Value root;
+            if (!ps.value(root) || root.kind != scenefile::Value::Obj) { std::fprintf(stderr, "rt_cli: %s: %s\n", argv[i], ps.err.empty() ? "not a JSON object" : ps.err.c_str()); return 2; }
+            for (const auto &kv : root.obj) {
+                const std::string &k = kv.first; const scenefile::Value &v = kv.second;
+                bool ok = true;
+                if (k == "obj") { useBVH = 1; if (v.kind == scenefile::Value::Str) objs.push_back(v.str); else if (v.kind == scenefile::Value::Arr) for (const auto &e : v.arr) { ok = ok && e.kind == scenefile::Value::Str; objs.push_back(e.str); } else ok = false; }
+                else if (k == "env") { ok = v.kind == scenefile::Value::Str; env = v.str; }
+                else if (k == "out") { ok = v.kind == scenefile::Value::Str; out = v.str; }
+                else if (k == "size") { ok = v.kind == scenefile::Value::Arr && v.arr.size() == 2; if (ok) { W = (int)v.arr[0].num; H = (int)v.arr[1].num; } }
+                else if (k == "frames") frames = (int)v.num;
+                else if (k == "bvh") useBVH = v.num != 0;
+                else if (k == "motion") showMotion = v.num != 0;
+                else if (k == "camera") {
+                    ok = v.kind == scenefile::Value::Obj;
+                    for (const auto &ck : v.obj) {
+                        if (ck.first == "pos" && ck.second.kind == scenefile::Value::Arr && ck.second.arr.size() == 3) for (int q = 0; q < 3; ++q) cam.pos[q] = (float)ck.second.arr[(size_t)q].num;
+                        else if (ck.first == "yaw") cam.yaw = (float)ck.second.num;
+                        else if (ck.first == "pitch") cam.pitch = (float)ck.second.num;
+                        else if (ck.first == "fov") cam.fov = (float)ck.second.num;
+                        else if (ck.first == "aspect") { cam.aspect = (float)ck.second.num; aspectSet = true; }
+                        else ok = false;
+                    }
+                } else ok = scenefile::set_param(params, k, v);
+                if (!ok) { std::fprintf(stderr, "rt_cli: %s: bad or unknown key \"%s\"\n", argv[i], k.c_str()); return 2; }
+            }
+        }
+        else if (a == "--obj") { objs.push_back(next()); useBVH = 1; }
         else if (a == "--dump-targets") dumpTargets = true;
         else if (a == "--env") env = next();
         else if (a == "--out") out = next();
@@ -55,7 +158,8 @@ int main(int argc, char **argv) {
         else if (a == "--aspect") { cam.aspect = (float)std::atof(next()); aspectSet = true; }
         else { std::fprintf(stderr, "usage: rt_cli [--obj f.obj] [--env cross.png] [--size WxH] [--spp n] [--frames n] [--bvh|--analytic] [--motion]\n"
                                     "              [--cam x,y,z,yaw,pitch] [--fov deg] [--aspect a] [--exposure e] [--no-gi --no-ao --no-taa --no-svgf --no-env] [--out prefix]\n"
-                                    "              (--obj may be repeated; --dump-targets writes prefix_{color,motion,gpos,gnrm}.pfm)\n"); return a == "--help" ? 0 : 2; }
+                                    "              (--obj may be repeated; --dump-targets writes prefix_{color,motion,gpos,gnrm}.pfm; --scene file.json sets any of\n"
+                                    "               the above and every RenderParams field by name)\n"); return a == "--help" ? 0 : 2; }
     }
     if (!aspectSet) cam.aspect = (float)W / (float)H;
 

@@ -104,3 +104,41 @@ def test_cli_merges_several_obj_files_and_dumps_the_targets(tmp_path):
             want = r.read_target(which, rt.RT_FORMAT_F32)
             got = read_pfm(tmp_path / f"two_{name}.pfm")
             assert np.array_equal(got[:, :, :ch], want[:, :, :ch]), name
+
+
+def test_cli_rejects_bad_scene_files(tmp_path):
+    bad = tmp_path / "bad.json"
+    bad.write_text('{"sppPerFrame": 2, "noSuchField": 1}')
+    out = subprocess.run([str(CLI), "--scene", str(bad)], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 2 and "noSuchField" in out.stderr
+    bad.write_text('{"sppPerFrame": ')
+    out = subprocess.run([str(CLI), "--scene", str(bad)], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 2
+
+
+@pytest.mark.gpu
+def test_cli_scene_file_equals_the_flags(tmp_path):
+    """a JSON scene file (RenderParams field names + camera / size / frames / obj / env) drives the same frames as flags."""
+    import json
+    v, f = rt.meshgen.bunny_standin(2)
+    obj = tmp_path / "blob.obj"
+    rt.meshgen.write_obj(obj, v, f)
+    scene = {"obj": [str(obj)], "env": str(scenes.ASSETS / "Sky_16.png"), "size": [120, 72], "frames": 2, "sppPerFrame": 3, "enableAO": False,
+             "sunEnabled": 1, "sunYaw": 30.0, "sunColor": [1.0, 0.9, 0.8], "exposure": 1.25, "out": str(tmp_path / "a"),
+             "camera": {"pos": [-2, 1.5, 1.0], "yaw": -90, "pitch": 0, "fov": 55.0}}
+    (tmp_path / "scene.json").write_text(json.dumps(scene, indent=1))
+    a = subprocess.run([str(CLI), "--scene", str(tmp_path / "scene.json")], capture_output=True, text=True, timeout=300)
+    assert a.returncode == 0, a.stdout + a.stderr
+    p = rt.default_render_params()
+    p.sppPerFrame, p.enableAO, p.sunEnabled, p.sunYaw, p.exposure = 3, 0, 1, 30.0, 1.25
+    p.sunColor[0], p.sunColor[1], p.sunColor[2] = 1.0, 0.9, 0.8
+    c = scenes.camera("closeup", aspect=120 / 72)
+    c.fov = 55.0
+    with rt.Renderer() as r:
+        r.upload_bvh(*rt.build_bvh(rt.gather_triangles(*rt.load_obj(obj))))
+        r.upload_env(scenes.env_faces("Sky_16"))
+        r.resize(120, 72)
+        for _ in range(2):
+            r.render_ray(p, c, use_bvh=True)
+        want = r.present(p)[::-1]
+    assert np.array_equal(rt.load_png(tmp_path / "a.png"), want)
