@@ -143,6 +143,12 @@ int rt_upload_bvh(RtContext *ctx, const float *nodes12, int nNodes, const float 
  * (src/render/cubemap.cpp:7-31, 67-91): 6 faces in GL order +X -X +Y -Y +Z -Z, faceSize^2 texels of
  * `channels` (3 or 4) bytes, rows in upload order.  faces == NULL installs the 1x1 dummy
  * (128,128,255) of cubemap.cpp:13. */
+/* The same builder as rt_build_bvh (below), run on the context's GPU: identical node numbering, ranges and boxes and the same
+ * set of triangles in every leaf whenever no two triangles tie at a median; the order of triangles INSIDE a leaf differs
+ * (the reference's std::nth_element leaves it unspecified), so rt_build_bvh remains the bit-parity path and this the fast one.
+ * Returns the number of nodes (or a negative RtStatus); nodes12 needs room for 2*nTris nodes. */
+int rt_build_bvh_gpu(RtContext *ctx, const float *tris9, int nTris, float *nodes12, float *tris12);
+
 int rt_upload_env(RtContext *ctx, const uint8_t *faces, int faceSize, int channels);
 
 /* Replaces Accum::recreate + GBuffer::recreate (src/render/accum.cpp:106-, gbuffer.cpp:12-53):

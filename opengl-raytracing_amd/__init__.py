@@ -153,6 +153,7 @@ SIGNATURES = {
     "rt_destroy": (None, [C.c_void_p]),
     "rt_last_error": (C.c_char_p, [C.c_void_p]),
     "rt_upload_bvh": (C.c_int, [C.c_void_p, _FP, C.c_int, _FP, C.c_int]),
+    "rt_build_bvh_gpu": (C.c_int, [C.c_void_p, _FP, C.c_int, _FP, _FP]),
     "rt_upload_env": (C.c_int, [C.c_void_p, _U8P, C.c_int, C.c_int]),
     "rt_resize": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "rt_reset_accum": (C.c_int, [C.c_void_p]),
@@ -434,6 +435,17 @@ class Renderer:
         n, t = _f32(nodes12).reshape(-1, 12), _f32(tris12).reshape(-1, 12)
         self._check(lib().rt_upload_bvh(self._h, _fp(n), n.shape[0], _fp(t), t.shape[0]))
         self.n_nodes, self.n_tris = n.shape[0], t.shape[0]
+
+    def build_bvh_gpu(self, tris9):
+        """Median-split BVH built on this context's GPU -> (nodes12, tris12); same tree as build_bvh, leaf-internal order may differ."""
+        t = _f32(tris9).reshape(-1, 9)
+        n = t.shape[0]
+        nodes = np.zeros((max(2 * n, 1), 12), np.float32)
+        tris = np.zeros((max(n, 1), 12), np.float32)
+        k = lib().rt_build_bvh_gpu(self._h, _fp(t), n, _fp(nodes), _fp(tris))
+        if k < 0:
+            self._check(k)
+        return nodes[:k].copy(), tris[:n].copy()
 
     def upload_env(self, faces):
         if faces is None:

@@ -489,6 +489,14 @@ int rt_upload_bvh(RtContext *c, const float *nodes12, int nNodes, const float *t
     return RT_OK;
 }
 
+int rt_build_bvh_gpu(RtContext *c, const float *tris9, int nTris, float *nodes12, float *tris12) {
+    if (!c) return RT_ERR_INVALID;
+    const char *err = nullptr;
+    const int rc = rtl::build_bvh_gpu(c->cfg.device, tris9, nTris, nodes12, tris12, &err);
+    if (rc < 0) return fail(c, rc, "rt_build_bvh_gpu: %s", err ? err : "bad arguments");
+    return rc;
+}
+
 int rt_upload_env(RtContext *c, const uint8_t *faces, int faceSize, int channels) {
     if (!c) return RT_ERR_INVALID;
     (void)hipSetDevice(c->cfg.device);

@@ -111,6 +111,8 @@ struct RtWaveBuffers;   // rt_wave.hip
 namespace rtl {
 hipError_t launch_present(hipStream_t s, const rtd::FrameGeom &g, const uint2 *color, const uint32_t *motion, const uint2 *gpos,
                           const uint2 *gnrm, const RtPresentParams &p, uint32_t *outRGBA8, int gatheredBlockSlots = 0);
+// rt_bvh_gpu.hip: the reference's median-split builder on the device -> number of nodes or a negative RtStatus
+int build_bvh_gpu(int device, const float *tris9, int nTris, float *nodes12, float *tris12, const char **errOut);
 hipError_t launch_mega(hipStream_t s, const rtd::DevFrame *frame, rtd::Targets tg, unsigned long long *counters, bool count,
                        int stackDepth, int nLocalTiles);
 }
