@@ -194,11 +194,13 @@ def test_frame_gatherer_plumbing_on_a_one_rank_rccl_group():
     try:
         with rt.Renderer() as r:
             _setup(r, nodes, tris, faces, W, H)
-            g = FrameGatherer(r)
+            g = FrameGatherer(r, exchange_history=True)      # a no-op with one rank, but the code path must hold
             for frame in range(3):
                 r.render_frame(rt.frame_uniforms(p, cam, W, H, frame, True, nodes.shape[0], tris.shape[0]))
                 g.gather()
                 assert np.array_equal(g.frame_halfs(), r.read_target(rt.RT_TARGET_COLOR))
+            pp = rt.make_present_params(p, False, W, H)
+            assert np.array_equal(g.present(pp), r.present_with(pp))          # gather of all four targets + rt_present_gathered
         # all_reduce of the timing scalar as bench.py does
         t = torch.tensor([1.5], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
