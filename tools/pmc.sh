@@ -11,6 +11,8 @@ S[4]="TA_BUSY_avr TA_FLAT_READ_WAVEFRONTS_sum"
 S[5]="FETCH_SIZE"
 S[6]="WRITE_SIZE"
 S[7]="TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_PENDING_STALL_CYCLES_sum"
+S[8]="TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum GRBM_GUI_ACTIVE"
+S[9]="TCP_GATE_EN1_sum TCP_GATE_EN2_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum"
 for i in $SETS; do
   timeout -k 10 150 rocprofv3 --pmc ${S[$i]} --output-format csv -d $OUT/p$i -- python3 $GRAFT_REPO_ROOT/tools/prof_frames.py "$@" > $OUT/p$i.log 2>&1 || { echo "set $i failed"; tail -3 $OUT/p$i.log; }
 done
