@@ -248,6 +248,18 @@ void rt_stage_end(RtContext *c, int stage, int launches, hipStream_t on) {
         if (c->pending[i].stage == stage) { (void)hipEventRecord(c->pending[i].b, on ? on : c->stream); break; }
     c->stageLaunches[stage] += (uint64_t)launches;
 }
+// Long timed runs: fold the events that have completed into the totals so that the pending list stays short (no host sync).
+static void harvest_stage_events(RtContext *c) {
+    if (c->pending.size() < 1024) return;
+    size_t done = 0;
+    while (done < c->pending.size() && hipEventQuery(c->pending[done].b) == hipSuccess) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, c->pending[done].a, c->pending[done].b) == hipSuccess) c->stageMs[c->pending[done].stage] += ms;
+        c->freeEvents.emplace_back(c->pending[done].a, c->pending[done].b);
+        ++done;
+    }
+    c->pending.erase(c->pending.begin(), c->pending.begin() + (std::ptrdiff_t)done);
+}
 static void resolve_stage_events(RtContext *c) {
     (void)sync_all(c);
     for (auto &ev : c->pending) {
@@ -569,6 +581,7 @@ int rt_render_frame(RtContext *c, const RtUniforms *uIn) {
     if (!c || !uIn) return RT_ERR_INVALID;
     if (!c->sized) return fail(c, RT_ERR_STATE, "rt_render_frame before rt_resize");
     (void)hipSetDevice(c->cfg.device);
+    if (c->timing) harvest_stage_events(c);
     DevFrame fr;
     fr.u = *uIn;
     fr.u.frameIndex = c->frameIndex;
