@@ -7,6 +7,7 @@
 // Several --obj files are merged into one triangle soup before build_bvh (a multi-object scene, BASELINE config 5);
 // --dump-targets also writes the four render targets of the last frame as little-endian PFM (float, bottom row first).
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstddef>
@@ -95,6 +96,7 @@ int main(int argc, char **argv) {
     std::vector<std::string> objs;
     std::string env, out = "frame";
     bool dumpTargets = false;
+    float dt = 1.0f / 60.0f;   // seconds per frame for the point-light orbit
     int W = 1920, H = 1080, frames = 1, device = 0, useBVH = 0, showMotion = 0;
     RtRenderParams params;
     rt_default_render_params(&params);
@@ -120,6 +122,7 @@ int main(int argc, char **argv) {
                 else if (k == "out") { ok = v.kind == scenefile::Value::Str; out = v.str; }
                 else if (k == "size") { ok = v.kind == scenefile::Value::Arr && v.arr.size() == 2; if (ok) { W = (int)v.arr[0].num; H = (int)v.arr[1].num; } }
                 else if (k == "frames") frames = (int)v.num;
+                else if (k == "dt") dt = (float)v.num;
                 else if (k == "bvh") useBVH = v.num != 0;
                 else if (k == "motion") showMotion = v.num != 0;
                 else if (k == "camera") {
@@ -138,6 +141,7 @@ int main(int argc, char **argv) {
         }
         else if (a == "--obj") { objs.push_back(next()); useBVH = 1; }
         else if (a == "--dump-targets") dumpTargets = true;
+        else if (a == "--dt") dt = (float)std::atof(next());
         else if (a == "--env") env = next();
         else if (a == "--out") out = next();
         else if (a == "--size") { if (std::sscanf(next(), "%dx%d", &W, &H) != 2) { std::fprintf(stderr, "rt_cli: --size WxH\n"); return 2; } }
@@ -202,8 +206,18 @@ int main(int argc, char **argv) {
     if ((rc = rt_resize(ctx, W, H)) != RT_OK) die(ctx, "rt_resize", rc);
 
     const auto t0 = std::chrono::steady_clock::now();
-    for (int f = 0; f < frames; ++f)
+    for (int f = 0; f < frames; ++f) {
+        // point-light orbit animation, application.cpp:341-348 (deg/s * s), with a fixed time step instead of glfwGetTime()
+        if (params.pointLightOrbitEnabled) {
+            params.pointLightYaw += params.pointLightOrbitSpeed * dt;
+            if (params.pointLightYaw > 360.0f) params.pointLightYaw -= 360.0f;
+            if (params.pointLightYaw < -360.0f) params.pointLightYaw += 360.0f;
+        }
         if ((rc = rt_render_ray(ctx, &params, &cam, useBVH, showMotion, nullptr, nullptr)) != RT_OK) die(ctx, "rt_render_ray", rc);
+        // an orbiting light is dynamic geometry for the accumulation: the history is invalid after every frame (application.cpp:538-553)
+        const bool lightMoving = params.pointLightOrbitEnabled != 0 && std::fabs(params.pointLightOrbitSpeed) > 1e-5f && params.pointLightOrbitRadius > 0.0f;
+        if (lightMoving && f + 1 < frames && (rc = rt_reset_accum(ctx)) != RT_OK) die(ctx, "rt_reset_accum", rc);
+    }
     rt_synchronize(ctx);
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     std::printf("[ACCUM] %d frame(s) %dx%d spp=%d in %.2f ms (%.2f ms/frame)\n", frames, W, H, params.sppPerFrame, ms, ms / (frames > 0 ? frames : 1));

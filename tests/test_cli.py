@@ -142,3 +142,26 @@ def test_cli_scene_file_equals_the_flags(tmp_path):
             r.render_ray(p, c, use_bvh=True)
         want = r.present(p)[::-1]
     assert np.array_equal(rt.load_png(tmp_path / "a.png"), want)
+
+
+@pytest.mark.gpu
+def test_cli_point_light_orbit_follows_the_main_loop(tmp_path):
+    """application.cpp:341-348, 538-553: the orbit advances the light's yaw by speed * dt per frame and, being dynamic geometry,
+    resets the accumulation after every frame."""
+    W, H, frames, dt = 96, 64, 3, 0.05
+    args = [str(CLI), "--analytic", "--no-env", "--size", f"{W}x{H}", "--frames", str(frames), "--dt", str(dt), "--scene", str(tmp_path / "s.json"), "--out", str(tmp_path / "o")]
+    (tmp_path / "s.json").write_text('{"pointLightOrbitEnabled": 1, "pointLightOrbitSpeed": 90.0, "pointLightOrbitRadius": 1.5, "pointLightEnabled": 1}')
+    out = subprocess.run(args, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    p = rt.default_render_params()
+    p.enableEnvMap, p.pointLightOrbitEnabled, p.pointLightOrbitSpeed, p.pointLightOrbitRadius, p.pointLightEnabled = 0, 1, 90.0, 1.5, 1
+    c = scenes.camera("default", aspect=W / H)
+    with rt.Renderer() as r:
+        r.resize(W, H)
+        for f in range(frames):
+            p.pointLightYaw = np.float32(np.float32(p.pointLightYaw) + np.float32(90.0) * np.float32(dt))
+            r.render_ray(p, c, use_bvh=False)
+            if f + 1 < frames:
+                r.reset_accum()
+        want = r.present(p)[::-1]
+    assert np.array_equal(rt.load_png(tmp_path / "o.png"), want)
