@@ -228,6 +228,15 @@ int rt_present_gathered(RtContext *ctx, const RtPresentParams *p, const void *ga
 int rt_get_counters(RtContext *ctx, RtCounters *out);   /* needs countWork; totals since rt_reset_counters */
 int rt_reset_counters(RtContext *ctx);
 
+/* What rt_upload_bvh made of the scene: the device arrays of DESIGN.md 3 (64-byte two-child records for closest-hit rays, 128-byte
+ * four-child records for any-hit rays, 80-byte triangle-pair records, the reference's 48-byte triangles for normals) and their
+ * sizes -- the bytes a traversal launch has to bring in at most once (bench.py's HBM roofline). */
+typedef struct RtSceneInfo {
+    int32_t nNodes, nTris, nInner, treeDepth, nWide4, nPairs;
+    uint64_t bytesNodes2, bytesNodes4, bytesPairs, bytesTris;
+} RtSceneInfo;
+int rt_get_scene_info(const RtContext *ctx, RtSceneInfo *out);
+
 /* Rays the wavefront pipeline actually traversed since the last reset (identical rays of the reference -- the SPP
  * copies of a primary ray, the per-sample copies of the AO rays -- are traced once; disk-light shadow rays whose
  * weight is exactly zero are not traced at all).  RtCounters keeps counting in the reference's units.

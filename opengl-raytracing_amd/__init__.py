@@ -131,6 +131,11 @@ class RtTracedRays(_Struct):
         return self.primary + self.shadow + self.bounce + self.bounceShadow
 
 
+class RtSceneInfo(_Struct):
+    _fields_ = [(n, i32) for n in ("nNodes", "nTris", "nInner", "treeDepth", "nWide4", "nPairs")] + \
+               [(n, C.c_uint64) for n in ("bytesNodes2", "bytesNodes4", "bytesPairs", "bytesTris")]
+
+
 class RtPresentParams(_Struct):  # uniforms of shaders/rt/rt_present.frag:38-50
     _fields_ = _fields([("exposure", f32), ("showMotion", i32), ("motionScale", f32), ("resolution", (f32, 2)), ("varMax", f32), ("kVar", f32),
                         ("kColor", f32), ("kVarMotion", f32), ("kColorMotion", f32), ("svgfStrength", f32), ("enableSVGF", i32)])
@@ -174,6 +179,7 @@ SIGNATURES = {
     "rt_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "rt_get_counters": (C.c_int, [C.c_void_p, C.POINTER(RtCounters)]),
     "rt_reset_counters": (C.c_int, [C.c_void_p]),
+    "rt_get_scene_info": (C.c_int, [C.c_void_p, C.POINTER(RtSceneInfo)]),
     "rt_get_traced_rays": (C.c_int, [C.c_void_p, C.POINTER(RtTracedRays), C.c_int]),
     "rt_enable_stage_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "rt_get_stage_times": (C.c_int, [C.c_void_p, C.POINTER(RtStageTimes)]),
@@ -547,6 +553,11 @@ class Renderer:
 
     def reset_counters(self):
         self._check(lib().rt_reset_counters(self._h))
+
+    def scene_info(self) -> RtSceneInfo:
+        i = RtSceneInfo()
+        self._check(lib().rt_get_scene_info(self._h, C.byref(i)))
+        return i
 
     def traced_rays(self, reset=False) -> RtTracedRays:
         t = RtTracedRays()

@@ -41,6 +41,7 @@ struct RtContext {
     uchar4 *dEnv = nullptr;
     int envSize = 0;
     int nNodes = 0, nTris = 0, nInner = 0, rootRef = 0, rootRef4 = 0, treeDepth = 0;
+    size_t nWide4 = 0, nPairs = 0;   // records in dW4 / dPairs
     float rootMin[3] = {0, 0, 0}, rootMax[3] = {0, 0, 0};
     // frame state
     FrameGeom g{};
@@ -350,6 +351,7 @@ int rt_upload_bvh(RtContext *c, const float *nodes12, int nNodes, const float *t
     c->dWNodes = c->dW4 = c->dTris = c->dWNodesW = c->dPairs = nullptr;
     c->nNodes = c->nTris = c->nInner = 0;
     c->treeDepth = 0;
+    c->nWide4 = c->nPairs = 0;
     if (nNodes == 0 || nTris == 0) return RT_OK;
     if (nTris >= (1 << 28)) return fail(c, RT_ERR_UNSUPPORTED, "rt_upload_bvh: %d triangles exceed the 2^28 leaf encoding", nTris);
 
@@ -495,6 +497,7 @@ int rt_upload_bvh(RtContext *c, const float *nodes12, int nNodes, const float *t
     HIP_TRY(c, hipMemcpy(c->dWNodes, wn.data(), wn.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->dTris, tris12, (size_t)nTris * 12 * sizeof(float), hipMemcpyHostToDevice));
     c->nNodes = nNodes; c->nTris = nTris; c->nInner = nInner; c->treeDepth = depth;
+    c->nWide4 = w4.size() / 32; c->nPairs = pairs.size() / 20 - 8;
     c->rootRef = refOf(0);
     std::memcpy(c->rootMin, nodes12, 12);
     std::memcpy(c->rootMax, nodes12 + 4, 12);
@@ -804,7 +807,22 @@ int rt_get_counters(RtContext *c, RtCounters *out) {
 int rt_reset_counters(RtContext *c) {
     if (!c) return RT_ERR_INVALID;
     (void)hipSetDevice(c->cfg.device);
-    HIP_TRY(c, hipMemsetAsync(c->dCounters, 0, 16 * sizeof(unsigned long long), c->stream));
+    // frames still in flight on ANY lane add their atomics until they finish: drain all lanes, then clear synchronously
+    HIP_TRY(c, sync_all(c));
+    HIP_TRY(c, hipMemset(c->dCounters, 0, 16 * sizeof(unsigned long long)));
+    return RT_OK;
+}
+
+int rt_get_scene_info(const RtContext *c, RtSceneInfo *out) {
+    if (!c || !out) return RT_ERR_INVALID;
+    std::memset(out, 0, sizeof *out);
+    out->nNodes = c->nNodes; out->nTris = c->nTris; out->nInner = c->nInner; out->treeDepth = c->treeDepth;
+    if (c->nNodes == 0) return RT_OK;
+    out->nWide4 = (int32_t)c->nWide4; out->nPairs = (int32_t)c->nPairs;
+    out->bytesNodes2 = (uint64_t)std::max(c->nInner, 1) * 64;
+    out->bytesNodes4 = (uint64_t)c->nWide4 * 128;
+    out->bytesPairs = (uint64_t)c->nPairs * 80;
+    out->bytesTris = (uint64_t)c->nTris * 48;
     return RT_OK;
 }
 

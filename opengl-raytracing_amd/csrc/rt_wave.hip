@@ -819,7 +819,7 @@ void launch_trace(hipStream_t st, int cus, int depth, const DevFrame *fr, const 
 }  // namespace
 
 // -------------------------------------------------------------------------------------------------
-constexpr int kMaxLaunches = 256;   // trace launches per frame (1 + 3 per chunk) the cursor table is sized for
+constexpr int kMinLaunches = 256;   // trace launches per frame (1 + 3 per chunk) the cursor table starts with; grown on demand
 
 struct RtWave {
     std::string err;
@@ -831,6 +831,7 @@ struct RtWave {
     size_t chunkBytes = 0;    // bytes of the per-chunk arena
     void *frameArena = nullptr, *chunkArena = nullptr;
     uint32_t *counts = nullptr, *heads = nullptr;
+    int launchCap = 0, chunkCap = 0;     // trace launches `heads` holds cursors for / chunks `counts` holds bounce counters for
     unsigned long long *acc = nullptr;   // traced-ray tallies accumulated over frames
     unsigned long long *stats = nullptr; // RT_TRACE_STATS=1: 4 stages x 8 diagnostic sums
 };
@@ -875,8 +876,7 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
     const int A = (u.enableAO == 1) ? std::max(u.aoSamples, 0) : 0;
     const int S1 = A + 6 * SPP, S2 = 6 * SPP;
 
-    if (!w->counts) { W_TRY(hipMalloc(&w->counts, (64 + 4096) * sizeof(uint32_t))); W_TRY(hipMalloc(&w->heads, (size_t)kMaxLaunches * kHeadWords * sizeof(uint32_t)));
-        W_TRY(hipMalloc(&w->acc, 16 * sizeof(unsigned long long))); W_TRY(hipMemsetAsync(w->acc, 0, 16 * sizeof(unsigned long long), st)); }
+    if (!w->acc) { W_TRY(hipMalloc(&w->acc, 16 * sizeof(unsigned long long))); W_TRY(hipMemsetAsync(w->acc, 0, 16 * sizeof(unsigned long long), st)); }
     // per-frame arena: cand, primT, primTri, hits
     if (w->slotsCap < nSlots) {
         if (w->frameArena) (void)hipFree(w->frameArena);
@@ -921,10 +921,23 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
         wb.giPos = (int *)take(CH * (size_t)SPP * 4);
         wb.shT = (float *)take(CH * (size_t)S1 * 4); wb.giL = (float *)take(CH * (size_t)SPP * 4); wb.sh2T = (float *)take(CH * (size_t)S2 * 4);
     }
-    wb.counts = w->counts; wb.heads = w->heads;
     wb.CH = (uint32_t)CH; wb.A = A; wb.SPP = SPP;
     const int nChunks = (int)((nSlots + CH - 1) / CH);
-    if (1 + nChunks * 3 > kMaxLaunches) { w->err = "too many chunks for the cursor table; raise RT_QUEUE_BUDGET_MB"; return RT_ERR_UNSUPPORTED; }
+    // cursor table (one set of sharded cursors per trace launch) and per-chunk bounce counters: grown when a small queue budget
+    // cuts the frame into more chunks than seen so far (4K / 16 spp at RT_QUEUE_BUDGET_MB=128 is 491 chunks).  Both arrays are
+    // only touched by this lane's stream, which is drained first.
+    if (1 + nChunks * 3 > w->launchCap || nChunks > w->chunkCap) {
+        W_TRY(hipStreamSynchronize(st));
+        if (w->counts) (void)hipFree(w->counts);
+        if (w->heads) (void)hipFree(w->heads);
+        w->counts = w->heads = nullptr;
+        w->launchCap = w->chunkCap = 0;
+        const int lc = std::max(kMinLaunches, 1 + nChunks * 3), cc = std::max(4096, nChunks);
+        W_TRY(hipMalloc(&w->counts, (size_t)(64 + cc) * sizeof(uint32_t)));
+        W_TRY(hipMalloc(&w->heads, (size_t)lc * kHeadWords * sizeof(uint32_t)));
+        w->launchCap = lc; w->chunkCap = cc;
+    }
+    wb.counts = w->counts; wb.heads = w->heads;
 
     W_TRY(hipMemsetAsync(w->counts, 0, (size_t)(64 + nChunks) * sizeof(uint32_t), st));
     W_TRY(hipMemsetAsync(w->heads, 0, (size_t)(1 + nChunks * 3) * kHeadWords * sizeof(uint32_t), st));

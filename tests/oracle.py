@@ -37,6 +37,24 @@ def build():
     subprocess.run(["make", "-C", str(ORC_DIR)], check=True, capture_output=True)
 
 
+def build_native(out_dir=None):
+    """The same two sources with `-O3 -march=native` (SURVEY.md 8d's CPU-baseline flags), built ON THE MACHINE THAT RUNS IT
+    (an -march=native object from another host may not run here) -> path of liborc_native.so."""
+    out = Path(out_dir) if out_dir else ORC_DIR
+    target = out / "liborc_native.so"
+    subprocess.run(["make", "-C", str(ORC_DIR), "native", f"NATIVE_OUT={target}"], check=True, capture_output=True)
+    return target
+
+
+def load(path):
+    """A second, independently loaded oracle library with the signatures of render() set (the CPU-baseline build)."""
+    L = C.CDLL(str(path))
+    L.orc_render.restype = C.c_int
+    L.orc_render.argtypes = [C.POINTER(rt.RtUniforms), _FP, _FP, _U8P, C.c_int, C.c_int, _U16P, _U16P, _U16P, _U16P, _U16P,
+                             C.c_int, C.c_int, C.c_int, C.c_int, _U8P, C.c_int, C.POINTER(OrcCounters)]
+    return L
+
+
 def lib():
     global _lib
     if _lib is not None:
@@ -175,8 +193,8 @@ def cubemap_from_cross(img):
     return faces
 
 
-def render(u, nodes12=None, tris12=None, env_faces=None, prev=None, region=None, mask=None, nthreads=8):
-    """One frame by the oracle -> ([color, motion, gpos, gnrm] uint16 arrays HxWxC, OrcCounters)."""
+def render(u, nodes12=None, tris12=None, env_faces=None, prev=None, region=None, mask=None, nthreads=8, L=None):
+    """One frame by the oracle -> ([color, motion, gpos, gnrm] uint16 arrays HxWxC, OrcCounters).  L: a library from load()."""
     W, H = int(u.resolution[0]), int(u.resolution[1])
     outs = [np.zeros((H, W, c), np.uint16) for c in (4, 2, 4, 4)]
     n = None if nodes12 is None else _f32(nodes12)
@@ -186,7 +204,7 @@ def render(u, nodes12=None, tris12=None, env_faces=None, prev=None, region=None,
     m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
     x0, y0, x1, y1 = region if region else (0, 0, W, H)
     cnt = OrcCounters()
-    rc = lib().orc_render(C.byref(u), None if n is None else _fp(n), None if t is None else _fp(t),
+    rc = (L or lib()).orc_render(C.byref(u), None if n is None else _fp(n), None if t is None else _fp(t),
                           None if e is None else e.ctypes.data_as(_U8P), 0 if e is None else e.shape[1], 0 if e is None else e.shape[3],
                           None if p is None else p.ctypes.data_as(_U16P), *[o.ctypes.data_as(_U16P) for o in outs],
                           x0, y0, x1, y1, None if m is None else m.ctypes.data_as(_U8P), nthreads, C.byref(cnt))

@@ -26,4 +26,8 @@ for k, d in agg.items():
     if "FETCH_SIZE" in d or "WRITE_SIZE" in d:
         tr[k] = {"fetch_kb_raw_per_frame": d.get("FETCH_SIZE", 0) / frames, "write_kb_per_frame": d.get("WRITE_SIZE", 0) / frames,
                  "hbm_bytes_per_frame_corrected": (2 * d.get("FETCH_SIZE", 0) + d.get("WRITE_SIZE", 0)) * 1024 / frames}
-json.dump({"frames_profiled": frames, "kernels": tr}, open(out + "/traffic.json", "w"), indent=1)
+import hashlib, pathlib
+h = hashlib.sha256()
+for f in sorted((pathlib.Path(__file__).resolve().parent.parent / "opengl-raytracing_amd" / "csrc").glob("*.h*")):   # = bench.py kernel_source_sha()
+    h.update(f.name.encode()); h.update(f.read_bytes())
+json.dump({"frames_profiled": frames, "kernel_source_sha256": h.hexdigest(), "commit": None, "kernels": tr}, open(out + "/traffic.json", "w"), indent=1)
