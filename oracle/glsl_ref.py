@@ -18,9 +18,11 @@ What is changed in the shader text at load time, and nothing else:
     (which derives the three clip-space corners (-1,-1) (3,-1) (-1,3) from gl_VertexID, :30-45) collapses to
     a degenerate triangle.  The same three corners are fed through a vertex attribute instead and
     vUV = 0.5 * (p + 1.0) is computed as at :44.  The fragment stage -- the hot path -- is untouched.
-  * SwiftShader 4.1 cannot execute the BVH traversal loops of rt_bvh.glsl:193-304 (see bvh_kat below): full frames
-    are produced for the analytic scene (uUseBVH = 0) and the present pass; of the BVH path its building blocks
-    nodeFetch / triFetch / aabbHit / triHit are executed one call per case.
+  * SwiftShader 4.1 mis-executes `continue` inside a `while` loop (minimal reproducer without any reference text:
+    tests/golden/swiftshader_continue_defect.py, log beside it), which is what broke traceBVH / traceBVHShadow
+    (rt_bvh.glsl:208,272) in round 1.  With rewrite_continue=True the two `if (C) continue;` statements become
+    `if (!(C)) { rest of the loop body }` (structured_continue below: same condition, same evaluation order, same statements
+    executed) and the traversal loops, BVH frames included, run.  Analytic frames and the present pass need no rewrite.
 All fragment arithmetic is the reference's.  SwiftShader's sin/cos/pow/exp2/log2/inversesqrt/normalize are its own
 approximations, so outputs agree with the oracle's float model to a tolerance, not to the bit, and the
 sin-based hash (rt_common.glsl) decorrelates the *noise* of stochastic terms: tests compare deterministic
@@ -107,11 +109,54 @@ def expand_includes(path):
     return "\n".join(out)
 
 
-def adapt(src):
+def structured_continue(src):
+    """`if (C) continue;` + rest of the loop body  ->  `if (!(C)) {` rest of the loop body `}`.
+
+    SwiftShader 4.1 mis-executes a `continue` in the `while (sp > 0)` traversal loops of rt_bvh.glsl:208,272: after the first
+    lane of a fragment quad takes it, loads in later iterations return garbage (minimal reproducer, independent of the
+    reference: tests/golden/swiftshader_continue_defect.py + .log).  The two statements are rewritten into the structured form
+    above -- C is evaluated once, in the same order, with the same short-circuiting, and exactly the same statements run when it
+    is false; no arithmetic changes.  Returns (text, number of statements rewritten)."""
+    lines = src.split("\n")
+    n = 0
+    i = 0
+    while i < len(lines):
+        m = re.match(r"^(\s*)if \((.*)\) continue;\s*$", lines[i])
+        if not m:
+            i += 1
+            continue
+        depth, j, closed = 0, i + 1, False
+        while j < len(lines) and not closed:
+            code = lines[j].split("//")[0]
+            for ch in code:
+                if ch == "{":
+                    depth += 1
+                elif ch == "}":
+                    if depth == 0:
+                        closed = True
+                        break
+                    depth -= 1
+            if not closed:
+                j += 1
+        if not closed:
+            raise RuntimeError("structured_continue: no enclosing loop end for line %d" % (i + 1))
+        lines[i] = "%sif (!(%s)) {" % (m.group(1), m.group(2))
+        lines.insert(j, m.group(1) + "}")
+        n += 1
+        i += 1
+    return "\n".join(lines), n
+
+
+def adapt(src, rewrite_continue=False):
     lines = src.split("\n")
     if not lines[0].startswith("#version 410"):
         raise RuntimeError("unexpected first line: " + lines[0])
-    return _PREAMBLE + "\n".join(lines[1:])
+    body = "\n".join(lines[1:])
+    if rewrite_continue:
+        body, n = structured_continue(body)
+        if n != 2:
+            raise RuntimeError("expected the two `continue` statements of rt_bvh.glsl:208,272, rewrote %d" % n)
+    return _PREAMBLE + body
 
 
 class GlslReference:
@@ -187,7 +232,8 @@ class GlslReference:
 
     # ---- GL helpers
     def _compile(self, kind, name):
-        return self._compile_src(kind, adapt(expand_includes(os.path.join(self.dir, name))).encode(), name)
+        # rt.frag carries the two traversal loops; everything else compiles from the unmodified text
+        return self._compile_src(kind, adapt(expand_includes(os.path.join(self.dir, name)), rewrite_continue=(name == "rt.frag")).encode(), name)
 
     def _compile_src(self, kind, src, name):
         gl = self.gl
@@ -396,11 +442,8 @@ class GlslReference:
         self._delete(tin + [out])
         return buf
 
-    # ---- per-function vectors for the BVH primitives.  SwiftShader 4.1 mis-executes the reference's traversal loops
-    # (a dynamic `for` nested in a `while` with `continue`, rt_bvh.glsl:205-241: node fetches inside return garbage and the
-    # run crashes intermittently), so traceBVH / traceBVHShadow cannot be executed here; their building blocks can:
-    # nodeFetch, triFetch, aabbHit and triHit are called straight from a small main() appended to the reference's
-    # rt_uniforms.glsl + rt_common.glsl + rt_bvh.glsl text.
+    # ---- per-function vectors for the BVH primitives: nodeFetch, triFetch, aabbHit and triHit are called straight from a
+    # small main() appended to the reference's rt_uniforms.glsl + rt_common.glsl + rt_bvh.glsl text (unmodified: no loop runs).
     _KAT_MAIN = """
 uniform samplerBuffer uKatRays;   // 2 texels per case: (ro, tMax), (rd, 0)
 uniform int uKatWidth;
@@ -463,6 +506,81 @@ void main() {
         gl.glDrawArrays(0x0004, 0, 3)
         gl.glFinish()
         self._check("kat draw")
+        res = []
+        for i in range(3):
+            gl.glReadBuffer(GL_COLOR_ATTACHMENT0 + i)
+            buf = np.zeros((H, W, 4), np.float32)
+            gl.glReadPixels(0, 0, W, H, GL_RGBA, GL_FLOAT, buf.ctypes.data_as(C.c_void_p))
+            res.append(buf.reshape(-1, 4)[:n].copy())
+        gl.glBindFramebuffer(GL_FRAMEBUFFER, 0)
+        gl.glDeleteFramebuffers(1, C.byref(fbo))
+        self._delete(texs + outs)
+        return res
+
+    # ---- the traversal loops themselves: traceBVH (rt_bvh.glsl:193-243) and traceBVHShadow (:260-304), one ray per fragment,
+    # called from a main() appended to the reference's rt_uniforms.glsl + rt_common.glsl + rt_bvh.glsl text with the two
+    # `continue` statements in structured form (structured_continue).  Outputs are fp32: nothing is hidden by fp16 rounding.
+    _TRACE_MAIN = """
+uniform samplerBuffer uKatRays;   // 2 texels per ray: (ro, tMax of the shadow query), (rd, 0)
+uniform int uKatWidth;
+layout(location = 0) out vec4 o0;
+layout(location = 1) out vec4 o1;
+layout(location = 2) out vec4 o2;
+void main() {
+    int i = int(gl_FragCoord.x) + int(gl_FragCoord.y) * uKatWidth;
+    vec4 a = texelFetch(uKatRays, 2 * i), b = texelFetch(uKatRays, 2 * i + 1);
+    Hit h;
+    h.t = -1.0; h.p = vec3(-2.0); h.n = vec3(-3.0); h.mat = -7;
+    bool hit = traceBVH(a.xyz, b.xyz, h);
+    bool occ = traceBVHShadow(a.xyz, b.xyz, a.w);
+    o0 = vec4(hit ? 1.0 : 0.0, h.t, occ ? 1.0 : 0.0, float(h.mat));
+    o1 = vec4(h.p, 0.0);
+    o2 = vec4(h.n, 0.0);
+}
+"""
+
+    def bvh_trace_kat(self, nodes12, tris12, rays8, eps, inf):
+        """Ray i: traceBVH(ro, rd) and traceBVHShadow(ro, rd, tMax_i) over the given BVH.  rays8: n x 8 floats (ro, tMax, rd, 0).
+        -> (o0, o1, o2) n x 4 float32: (hit, t, occluded, mat), (p, 0), (n, 0)."""
+        gl = self.gl
+        n = rays8.shape[0]
+        W = 64
+        H = (n + W - 1) // W
+        if not hasattr(self, "prog_trace"):
+            body = "\n".join(open(os.path.join(self.dir, f)).read() for f in ("rt_uniforms.glsl", "rt_common.glsl", "rt_bvh.glsl"))
+            body, nrew = structured_continue(body)
+            if nrew != 2:
+                raise RuntimeError("expected the two `continue` statements of rt_bvh.glsl:208,272, rewrote %d" % nrew)
+            vs = self._compile_src(GL_VERTEX_SHADER, _FULLSCREEN_VS.encode(), "fullscreen corners")
+            fs = self._compile_src(GL_FRAGMENT_SHADER, (_PREAMBLE + body + self._TRACE_MAIN).encode(), "bvh trace kat")
+            self.prog_trace = self._link(vs, fs)
+        rr = np.zeros((W * H, 8), np.float32)
+        rr[:n] = rays8
+        rr[n:, 4:7] = 1.0
+        texs = [self._tbo(nodes12), self._tbo(tris12), self._tbo(rr)]
+        outs = [self._tex2d(GL_RGBA32F, W, H, GL_RGBA, GL_FLOAT, None) for _ in range(3)]
+        fbo = C.c_uint()
+        gl.glGenFramebuffers(1, C.byref(fbo))
+        gl.glBindFramebuffer(GL_FRAMEBUFFER, fbo)
+        for i, t in enumerate(outs):
+            gl.glFramebufferTexture2D(GL_FRAMEBUFFER, GL_COLOR_ATTACHMENT0 + i, GL_TEXTURE_2D, t, 0)
+        bufs = (C.c_uint * 3)(*[GL_COLOR_ATTACHMENT0 + i for i in range(3)])
+        gl.glDrawBuffers(3, bufs)
+        if gl.glCheckFramebufferStatus(GL_FRAMEBUFFER) != GL_FRAMEBUFFER_COMPLETE:
+            raise RuntimeError("trace KAT FBO incomplete")
+        gl.glViewport(0, 0, W, H)
+        p = self.prog_trace
+        gl.glUseProgram(p)
+        self._bind_sampler(p, "uBvhNodes", 1, GL_TEXTURE_2D, texs[0])
+        self._bind_sampler(p, "uBvhTris", 2, GL_TEXTURE_2D, texs[1])
+        self._bind_sampler(p, "uKatRays", 3, GL_TEXTURE_2D, texs[2])
+        for nm, v in (("uKatWidth", W), ("uNodeCount", nodes12.shape[0]), ("uTriCount", tris12.shape[0])):
+            gl.glUniform1i(gl.glGetUniformLocation(p, nm.encode()), int(v))
+        gl.glUniform1f(gl.glGetUniformLocation(p, b"uEPS"), float(eps))
+        gl.glUniform1f(gl.glGetUniformLocation(p, b"uINF"), float(inf))
+        gl.glDrawArrays(0x0004, 0, 3)
+        gl.glFinish()
+        self._check("trace kat draw")
         res = []
         for i in range(3):
             gl.glReadBuffer(GL_COLOR_ATTACHMENT0 + i)

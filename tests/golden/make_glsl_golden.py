@@ -5,7 +5,8 @@ SwiftShader libraries inside the `kaleido` wheel); the fixtures it writes are pl
 (uniform block bytes, BVH arrays, cube-map faces, previous-frame accumulation) and the four render
 targets the reference shader produced, as float16 bit patterns.
 
-    python tests/golden/make_glsl_golden.py       # rewrites tests/golden/glsl_*.npz and prints agreement with the oracle
+    python tests/golden/make_glsl_golden.py           # rewrites tests/golden/glsl_*.npz and prints agreement with the oracle
+    python tests/golden/make_glsl_golden.py H I       # only the named sections (A-G: round 1, H-I: the BVH traversal loops)
 
 Frame f of a fixture was rendered with `prev` = the shader's own COLOR0 of frame f-1 (stored as color{f-1}),
 so checkers feed every implementation the same history and compare frame by frame without drift.
@@ -83,10 +84,134 @@ def moving_pair(p, cam0, cam1, w, h, use_bvh=False, **kw):
     return us
 
 
+def crate_mesh(nx=8, ny=8, seed=7, layers=(0.0, -4.0)):
+    """Height field over an integer grid, heights in {0,1,2}, two layers, cells split along alternating diagonals: every
+    coordinate is a small integer, so Moller-Trumbore along axis directions is exact and rays through shared edges hit two
+    triangles at bit-equal t -- the tie rule of triHit / traceBVH (`tt > tMax` rejects, so the LATER triangle wins,
+    rt_bvh.glsl:166,218) and the equal-tmin push order (`tminL < tminR`, :233) decide the returned normal."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for layer, z0 in enumerate(layers):
+        h = rng.integers(0, 3, size=(nx + 1, ny + 1)).astype(np.float32) + np.float32(z0)
+        for x in range(nx):
+            for y in range(ny):
+                def P(i, j):
+                    return np.array([x + i, y + j, h[x + i, y + j]], np.float32)
+                if (x + y + layer) % 2 == 0:
+                    cell = [(P(0, 0), P(1, 0), P(1, 1)), (P(0, 0), P(1, 1), P(0, 1))]
+                else:
+                    cell = [(P(0, 0), P(1, 0), P(0, 1)), (P(1, 0), P(1, 1), P(0, 1))]
+                for a, b, c in cell:
+                    out.append(np.concatenate([a, b - a, c - a]))
+    return np.array(out, np.float32)
+
+
+def trace_kat(g):
+    """H. traceBVH / traceBVHShadow executed ray by ray (oracle/glsl_ref.py bvh_trace_kat)."""
+    d = {}
+    eps_inf = orc.frame_uniforms(orc.default_render_params(), orc.default_camera(), 8, 8, 0, False)
+    # H1: exact-arithmetic mesh, axis rays through edges / cell interiors (ties, rdInv = +-inf), up and down
+    nodes, tris = orc.build_bvh(crate_mesh())
+    rays = []
+    for x in range(8):
+        for y in range(8):
+            for fx, fy in ((0.5, 0.5), (0.25, 0.25), (0.75, 0.75), (0.25, 0.75), (0.75, 0.25), (0.25, 0.5), (0.0, 0.0), (0.5, 0.0), (0.0, 0.25)):
+                rays.append(((x + fx, y + fy, 8.0), (0.0, 0.0, -1.0)))
+                rays.append(((x + fx, y + fy, -12.0), (0.0, 0.0, 1.0)))
+    for k in range(64):                         # sideways: two infinite slab axes at once
+        rays.append(((-3.0, 0.125 + 0.25 * (k % 31), -3.875 + 0.25 * (k // 2)), (1.0, 0.0, 0.0)))
+        rays.append(((0.375 + 0.25 * (k % 29), 11.0, -3.625 + 0.25 * (k // 2)), (0.0, -1.0, 0.0)))
+    r8 = np.zeros((len(rays), 8), np.float32)
+    for i, (o, dd) in enumerate(rays):
+        r8[i, 0:3], r8[i, 4:7] = o, dd
+        r8[i, 3] = (9.0, 6.5, 14.0, 2.0)[i % 4]
+    d["crate"] = (nodes, tris, r8)
+    # H2: a generic mesh (bunny stand-in, 320 triangles, depth-7 tree), rays in general position + axis-parallel components
+    v, fidx = rt.meshgen.bunny_standin(2)
+    nodes, tris = orc.build_bvh(orc.gather_triangles(v, fidx))
+    rng = np.random.default_rng(29)
+    n = 1536
+    centre = 0.5 * (nodes[0, 0:3] + nodes[0, 4:7])
+    ro = (centre + rng.normal(0, 1, (n, 3)) * 1.2).astype(np.float32)
+    ro[: n // 8] = (centre + rng.normal(0, 0.1, (n // 8, 3))).astype(np.float32)          # origins inside the mesh
+    tgt = tris[rng.integers(tris.shape[0], size=n), 0:3] + rng.normal(0, 0.15, (n, 3))
+    rd = tgt - ro
+    rd = (rd / np.linalg.norm(rd, axis=1, keepdims=True)).astype(np.float32)
+    for i in range(0, n, 13):
+        rd[i, i % 3] = 0.0                                                                # rdInv = inf on one axis
+    r8 = np.zeros((n, 8), np.float32)
+    r8[:, 0:3], r8[:, 4:7] = ro, rd
+    r8[:, 3] = rng.uniform(0.2, 4.0, n).astype(np.float32)
+    d["bunny"] = (nodes, tris, r8)
+    save = {"eps": np.float32(eps_inf.eps), "inf": np.float32(eps_inf.inf)}
+    for tag, (nodes, tris, r8) in d.items():
+        o0, o1, o2 = g.bvh_trace_kat(nodes, tris, r8, eps_inf.eps, eps_inf.inf)
+        u = orc.frame_uniforms(orc.default_render_params(), orc.default_camera(), 8, 8, 0, True, nodes.shape[0], tris.shape[0])
+        nan_slab = np.zeros(r8.shape[0], np.uint8)
+        ties = np.zeros(r8.shape[0], np.uint8)
+        agree = {"hit": 0, "t_exact": 0, "t_close": 0, "normal": 0, "occ": 0, "hits": 0}
+        for i in range(r8.shape[0]):
+            o, dd = r8[i, 0:3], r8[i, 4:7]
+            # 0 * inf = NaN in a slab: the ray lies IN a box plane of an axis it does not move along.  GLSL leaves min/max of a
+            # NaN to the driver (SwiftShader: SSE minps/maxps; the oracle models v_min_f32 / v_max_f32) -- recorded, not compared.
+            for ax in range(3):
+                if dd[ax] == 0.0 and (np.any(nodes[:, ax] == o[ax]) or np.any(nodes[:, 4 + ax] == o[ax])):
+                    nan_slab[i] = 1
+            hit, t, pp, nn, _ = orc.trace_bvh(u, nodes, tris, o, dd)
+            occ = orc.trace_bvh_shadow(u, nodes, tris, o, dd, float(r8[i, 3]))
+            if hit:
+                same = sum(1 for k in range(tris.shape[0]) if (lambda r: r[0] and r[1] == np.float32(t))(orc.tri_hit(u, o, dd, tris[k], 1e30)))
+                ties[i] = min(same, 255)
+            if nan_slab[i]:
+                continue
+            agree["hit"] += bool(o0[i, 0]) == hit
+            agree["occ"] += bool(o0[i, 2]) == occ
+            if hit and o0[i, 0]:
+                agree["hits"] += 1
+                agree["t_exact"] += o0[i, 1] == np.float32(t)
+                agree["t_close"] += abs(o0[i, 1] - t) <= 2e-6 * abs(t)
+                agree["normal"] += np.abs(o2[i, 0:3] - nn).max() <= 1e-5
+        print(f"  trace kat {tag}: {r8.shape[0]} rays, {int(nan_slab.sum())} with a NaN slab (not compared), {int((ties > 1).sum())} with >= 2 triangles at the "
+              f"winning t; of the rest: {agree}")
+        save.update({f"{tag}_nodes12": nodes, f"{tag}_tris12": tris, f"{tag}_rays": r8, f"{tag}_o0": o0, f"{tag}_o1": o1, f"{tag}_o2": o2,
+                     f"{tag}_nan_slab": nan_slab, f"{tag}_ties": ties})
+    np.savez_compressed(HERE / "glsl_bvh_trace_kat.npz", **save)
+
+
+def bvh_frames(g, faces):
+    """I. whole BVH frames through rt.frag (uUseBVH = 1): primary traversal, shadow / bounce / AO rays, TAA."""
+    v, fidx = rt.meshgen.bunny_standin(3)                       # 1 280 triangles, 511 nodes
+    nodes, tris = orc.build_bvh(orc.gather_triangles(v, fidx))
+    # close-up camera (mesh ~45 % of the frame), 2 spp, defaults (GI + AO + sun + sky + point + env), 3 frames of TAA
+    W, H = 64, 48
+    p = orc.default_render_params(); p.sppPerFrame = 2
+    cam = orc.default_camera(); cam.pos[0], cam.pos[1], cam.pos[2], cam.yaw, cam.pitch, cam.aspect = -2.0, 1.5, 1.0, -90.0, 0.0, W / H
+    run(g, "glsl_bvh_closeup_64x48", [orc.frame_uniforms(p, cam, W, H, f, True, nodes.shape[0], tris.shape[0]) for f in range(3)], nodes, tris, faces)
+    # camera moves between frames 0 and 1: motion vectors on hits, reprojection, the (4,4) marker on misses; 1 spp, GI off
+    p = orc.default_render_params(); p.enableGI = 0
+    cam1 = orc.default_camera(); cam1.pos[0], cam1.pos[1], cam1.pos[2], cam1.yaw, cam1.pitch, cam1.aspect = -1.9, 1.55, 1.05, -91.5, -1.0, W / H
+    run(g, "glsl_bvh_moving_64x48", moving_pair(p, cam, cam1, W, H, True, node_count=nodes.shape[0], tri_count=tris.shape[0]), nodes, tris, faces)
+    # 5 120 triangles (depth-12 tree), reference default camera looking at the mesh from further away, 1 spp, gradient sky
+    v, fidx = rt.meshgen.bunny_standin(4)
+    nodes, tris = orc.build_bvh(orc.gather_triangles(v, fidx))
+    p = orc.default_render_params(); p.enableEnvMap = 0
+    cam = orc.default_camera(); cam.pos[0], cam.pos[1], cam.pos[2], cam.yaw, cam.pitch, cam.aspect = -2.0, 1.6, 2.2, -90.0, -3.0, W / H
+    run(g, "glsl_bvh_5k_gradient_64x48", [orc.frame_uniforms(p, cam, W, H, f, True, nodes.shape[0], tris.shape[0], env_loaded=False) for f in range(2)],
+        nodes, tris, None)
+
+
 def main():
     g = GlslReference()
     print("GL:", g.version)
     faces = ring_env(8, 11)
+    only = set(a.upper() for a in sys.argv[1:])
+    if only:
+        if "H" in only:
+            trace_kat(g)
+        if "I" in only:
+            bvh_frames(g, faces)
+        if only <= {"H", "I"}:
+            return
 
     # A. analytic scene, gradient sky, defaults (BASELINE config 1 in miniature), 3 frames of TAA
     p = orc.default_render_params(); p.enableEnvMap = 0
@@ -128,7 +253,7 @@ def main():
             pres[f"{k}_{tag}"] = a
     np.savez_compressed(HERE / "glsl_present_48x36.npz", **pres)
 
-    # F. BVH primitives, one call per case (the traversal loops themselves do not run on SwiftShader 4.1, see oracle/glsl_ref.py)
+    # F. BVH primitives, one call per case (the traversal loops: sections H and I)
     v, fidx = rt.meshgen.bunny_standin(3)
     nodes, tris = orc.build_bvh(orc.gather_triangles(v, fidx))
     n = min(nodes.shape[0], tris.shape[0], 1280)
@@ -194,6 +319,9 @@ def main():
         shade[f"u_{tag}"] = ubytes(u)
         shade[f"rad_{tag}"] = got
     np.savez_compressed(HERE / "glsl_bvh_shade_kat.npz", **shade)
+
+    trace_kat(g)
+    bvh_frames(g, faces)
 
 
 if __name__ == "__main__":

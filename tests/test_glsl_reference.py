@@ -15,7 +15,10 @@ import opengl_raytracing_amd as rt
 
 GOLDEN = Path(__file__).resolve().parent / "golden"
 FRAME_FIXTURES = ["glsl_analytic_gradient_64x48", "glsl_analytic_materials_env_48x36", "glsl_analytic_moving_48x36",
-                  "glsl_analytic_toggles_48x36"]
+                  "glsl_analytic_toggles_48x36",
+                  # rt.frag in BVH mode -- traceBVH / traceBVHShadow executed by the reference GLSL for every primary, shadow,
+                  # bounce and AO ray of the frame (round 2: oracle/glsl_ref.py structured_continue)
+                  "glsl_bvh_closeup_64x48", "glsl_bvh_moving_64x48", "glsl_bvh_5k_gradient_64x48"]
 RMSE_TOL = 1e-4
 EXACT_MIN = 0.99
 
@@ -42,7 +45,7 @@ def test_oracle_matches_reference_glsl_frames(orc, name):
     prev = None
     for f in range(d["uniforms"].shape[0]):
         u = rt.RtUniforms.from_buffer_copy(d["uniforms"][f].tobytes())
-        got, _ = orc.render(u, None, None, env, prev)
+        got, _ = orc.render(u, d["nodes12"] if "nodes12" in d else None, d["tris12"] if "tris12" in d else None, env, prev)
         check_targets(name, f, got, d)
         prev = d[f"color{f}"]          # the shader's own history, as in the fixture
 
@@ -68,8 +71,7 @@ def test_oracle_matches_reference_glsl_present(orc, tag):
 
 
 def test_oracle_matches_reference_glsl_bvh_primitives(orc):
-    """nodeFetch / triFetch / aabbHit / triHit of rt_bvh.glsl, one call per case (the traversal loops do not run on
-    SwiftShader 4.1: oracle/glsl_ref.py).  Slab tests must agree exactly; Moller-Trumbore t to a median relative error < 1e-6 (the oracle's
+    """nodeFetch / triFetch / aabbHit / triHit of rt_bvh.glsl, one call per case (the loops: ..._traversal_loops below).  Slab tests must agree exactly; Moller-Trumbore t to a median relative error < 1e-6 (the oracle's
     dot/cross use fmaf, SwiftShader's do not) with the hit decision allowed to differ only on constructed borderline cases."""
     d = np.load(GOLDEN / "glsl_bvh_kat.npz")
     nodes, tris, rays, o0, o1, o2 = (d[k] for k in ("nodes12", "tris12", "rays", "o0", "o1", "o2"))
@@ -98,6 +100,72 @@ def test_oracle_matches_reference_glsl_bvh_primitives(orc):
             assert np.max(np.abs(t[2:5] - o2[i, 0:3])) <= 1e-6, i
     assert hits > 100 and flag_diff <= n // 50, (hits, flag_diff)
     assert np.median(rel) < 1e-6 and np.percentile(rel, 95) < 5e-6
+
+
+def check_trace_kat(tag, d, closest, any_hit):
+    """closest(i) -> (hit, t, p[3], n[3]); any_hit(i) -> bool, for ray i of fixture section `tag`.  Shared with the GPU test.
+    Rays lying IN a box plane of an axis they do not move along make a slab product 0 * inf = NaN; GLSL leaves min/max of a NaN
+    to the driver (SURVEY.md 8a aabbHit), so those rays are recorded in the fixture but not compared."""
+    rays, o0, o1, o2, nan_slab, ties = (d[f"{tag}_{k}"] for k in ("rays", "o0", "o1", "o2", "nan_slab", "ties"))
+    exact_arith = tag == "crate"              # integer coordinates, axis rays: every product is exact, so t must be bit-identical
+    compared = hits = tie_rays = 0
+    for i in range(rays.shape[0]):
+        if nan_slab[i]:
+            continue
+        compared += 1
+        hit, t, p, n = closest(i)
+        assert bool(o0[i, 0]) == bool(hit), (tag, i, "hit")
+        assert bool(o0[i, 2]) == bool(any_hit(i)), (tag, i, "shadow")
+        if not hit:
+            assert o0[i, 1] == d["inf"] and o0[i, 3] == 1.0          # hitOut.t = uINF, mat = 1 are set before the loop (rt_bvh.glsl:195-197)
+            continue
+        hits += 1
+        tie_rays += ties[i] > 1
+        if exact_arith:
+            assert np.float32(t) == o0[i, 1], (tag, i, t, o0[i, 1])
+        else:
+            assert abs(t - o0[i, 1]) <= 5e-6 * abs(o0[i, 1]), (tag, i, t, o0[i, 1])
+        assert np.max(np.abs(np.asarray(n) - o2[i, 0:3])) <= 1e-5, (tag, i, n, o2[i])      # which triangle won, incl. equal-t ties
+        assert np.max(np.abs(np.asarray(p) - o1[i, 0:3])) <= 1e-5 * max(1.0, float(np.abs(o1[i, 0:3]).max())), (tag, i)
+        assert o0[i, 3] == 1.0
+    return compared, hits, tie_rays
+
+
+@pytest.mark.parametrize("tag", ["crate", "bunny"])
+def test_oracle_matches_reference_glsl_traversal_loops(orc, tag):
+    """traceBVH (rt_bvh.glsl:193-243) and traceBVHShadow (:260-304) executed ray by ray by the reference GLSL
+    (tests/golden/make_glsl_golden.py section H).  `crate`: exact-arithmetic height field, axis rays through shared edges:
+    hundreds of rays where two triangles have bit-equal t, so the returned normal shows the visit order, the pop-time cull and
+    the tie rule; rdInv = +-inf on two axes.  `bunny`: generic mesh, generic rays."""
+    d = np.load(GOLDEN / "glsl_bvh_trace_kat.npz")
+    nodes, tris, rays = d[f"{tag}_nodes12"], d[f"{tag}_tris12"], d[f"{tag}_rays"]
+    u = orc.frame_uniforms(orc.default_render_params(), orc.default_camera(), 8, 8, 0, True, nodes.shape[0], tris.shape[0])
+    assert u.eps == d["eps"] and u.inf == d["inf"]
+
+    def closest(i):
+        hit, t, p, n, _ = orc.trace_bvh(u, nodes, tris, rays[i, 0:3], rays[i, 4:7])
+        return hit, t, p, n
+
+    compared, hits, tie_rays = check_trace_kat(tag, d, closest, lambda i: orc.trace_bvh_shadow(u, nodes, tris, rays[i, 0:3], rays[i, 4:7], float(rays[i, 3])))
+    assert compared >= 1000 and hits >= 900
+    if tag == "crate":
+        assert tie_rays >= 300, tie_rays
+
+
+def test_structured_continue_rewrite():
+    """The one load-time change to the traversal functions' text (oracle/glsl_ref.py): `if (C) continue;` followed by the rest
+    of the loop body becomes `if (!(C)) {` rest `}` -- checked here on a stand-alone snippet (the reference is not readable
+    from the test suite)."""
+    import sys
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "oracle"))
+    import glsl_ref
+    src = "void f() {\n    while (sp > 0) {\n        int ni = stack[--sp];\n        if (!hit(ni) || t > best) continue;\n\n        if (leaf) {\n            g();   // }\n        } else {\n            h();\n        }\n    }\n    return;\n}"
+    out, n = glsl_ref.structured_continue(src)
+    assert n == 1
+    assert out.split("\n") == ["void f() {", "    while (sp > 0) {", "        int ni = stack[--sp];", "        if (!(!hit(ni) || t > best)) {", "",
+                               "        if (leaf) {", "            g();   // }", "        } else {", "            h();", "        }", "        }", "    }",
+                               "    return;", "}"]
+    assert glsl_ref.structured_continue("x = 1;\ncontinue_label();")[1] == 0
 
 
 @pytest.mark.parametrize("tag", ["default", "disk_light_only", "no_env_gi_only"])

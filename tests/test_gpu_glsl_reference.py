@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import opengl_raytracing_amd as rt
-from test_glsl_reference import FRAME_FIXTURES, check_targets
+from test_glsl_reference import FRAME_FIXTURES, check_targets, check_trace_kat
 
 pytestmark = pytest.mark.gpu
 GOLDEN = Path(__file__).resolve().parent / "golden"
@@ -27,6 +27,8 @@ def test_hip_matches_reference_glsl_frames(ren, name):
     u0 = rt.RtUniforms.from_buffer_copy(d["uniforms"][0].tobytes())
     ren.resize(int(u0.resolution[0]), int(u0.resolution[1]))
     ren.upload_env(d["env"] if "env" in d else None)
+    if "nodes12" in d:
+        ren.upload_bvh(d["nodes12"], d["tris12"])
     ren.reset_accum()
     for f in range(d["uniforms"].shape[0]):
         u = rt.RtUniforms.from_buffer_copy(d["uniforms"][f].tobytes())
@@ -34,6 +36,37 @@ def test_hip_matches_reference_glsl_frames(ren, name):
             ren.write_target(rt.RT_TARGET_COLOR, d[f"color{f - 1}"])      # the shader's own history, as in the fixture
         ren.render_frame(u)
         check_targets(name, f, ren.read_all(), d)
+
+
+@pytest.mark.parametrize("name", [n for n in FRAME_FIXTURES if "_bvh_" in n])
+def test_hip_megakernel_matches_reference_glsl_bvh_frames(name):
+    """The default renderer takes the wavefront pipeline for BVH frames (test above); the same fixtures through the megakernel."""
+    d = np.load(GOLDEN / f"{name}.npz")
+    u0 = rt.RtUniforms.from_buffer_copy(d["uniforms"][0].tobytes())
+    with rt.Renderer(pipeline=rt.RT_PIPELINE_MEGAKERNEL) as r:
+        r.resize(int(u0.resolution[0]), int(u0.resolution[1]))
+        r.upload_env(d["env"] if "env" in d else None)
+        r.upload_bvh(d["nodes12"], d["tris12"])
+        for f in range(d["uniforms"].shape[0]):
+            if f > 0:
+                r.write_target(rt.RT_TARGET_COLOR, d[f"color{f - 1}"])
+            r.render_frame(rt.RtUniforms.from_buffer_copy(d["uniforms"][f].tobytes()))
+            check_targets(name, f, r.read_all(), d)
+
+
+@pytest.mark.parametrize("tag", ["crate", "bunny"])
+def test_hip_matches_reference_glsl_traversal_loops(ren, tag):
+    """rt_debug_trace (the device traversal) against traceBVH / traceBVHShadow as the reference GLSL executed them."""
+    d = np.load(GOLDEN / "glsl_bvh_trace_kat.npz")
+    nodes, tris, rays = d[f"{tag}_nodes12"], d[f"{tag}_tris12"], d[f"{tag}_rays"]
+    ren.upload_bvh(nodes, tris)
+    eps, inf = float(d["eps"]), float(d["inf"])
+    c = ren.debug_trace(0, rays[:, 0:3], rays[:, 4:7], eps=eps, inf=inf)
+    a = ren.debug_trace(1, rays[:, 0:3], rays[:, 4:7], rays[:, 3], eps=eps, inf=inf)
+    compared, hits, tie_rays = check_trace_kat(tag, d, lambda i: (c[i, 0] < np.float32(inf), c[i, 0], c[i, 1:4], c[i, 4:7]), lambda i: a[i, 0] != 0.0)
+    assert compared >= 1000 and hits >= 900
+    if tag == "crate":
+        assert tie_rays >= 300
 
 
 @pytest.mark.parametrize("tag", ["svgf", "plain", "motion", "svgf_moving"])

@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 has() { [[ " $STEPS " == *" $1 "* ]]; }
 pmc() {   # pmc <outdir> <counters...> -- <program...>
   local d=$1; shift; local c=(); while [[ "$1" != "--" ]]; do c+=("$1"); shift; done; shift
-  timeout -k 10 240 rocprofv3 --pmc "${c[@]}" --output-format csv -d $d -- "$@" > $d.log 2>&1 || { echo "pmc pass $d failed"; tail -3 $d.log; }
+  mkdir -p $(dirname $d); timeout -k 10 240 rocprofv3 --pmc "${c[@]}" --output-format csv -d $d -- "$@" > $d.log 2>&1 || { echo "pmc pass $d failed"; tail -3 $d.log; }
 }
 if has tests; then
   (cd $R && timeout -k 10 900 python3 -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1); echo "pytest rc=$?"; tail -3 $OUT/pytest.log
