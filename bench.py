@@ -72,6 +72,9 @@ def main():
     ap.add_argument("--pipeline", default="auto", choices=["auto", "mega", "wave"])
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of EACH oracle (CPU baseline) sample -- one thread, then all cores; 0 = skip")
     ap.add_argument("--no-default-camera", action="store_true")
+    ap.add_argument("--gather-every", type=int, default=1, help="N > 1 GPUs: gather COLOR0 to rank 0 every k-th frame (1 = every frame; a static "
+                    "camera's history is tile-local, so BASELINE configs[4] needs one gather per 32 accumulated frames)")
+    ap.add_argument("--gather", default="native", choices=["native", "torch"], help="N > 1: the library's own RCCL communicator (C ABI) or torch.distributed")
     # other BASELINE.json configurations, for side measurements (the default line is configs[1], the one `metric` is quoted on)
     ap.add_argument("--size", default="1920x1080", help="framebuffer WxH (configs[3]: 3840x2160)")
     ap.add_argument("--spp", type=int, default=4, help="samples per pixel and frame (configs[2-3]: 16, configs[4]: 64)")
@@ -84,7 +87,7 @@ def main():
     import torch
     import torch.distributed as dist
     import opengl_raytracing_amd as rt
-    from opengl_raytracing_amd.dist_gather import FrameGatherer
+    from opengl_raytracing_amd.dist_gather import FrameGatherer, NativeGatherer
     import scenes
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -111,6 +114,8 @@ def main():
     params.sppPerFrame = SPP
     npix = W * H
 
+    gather_path = {"path": "library-owned RCCL communicator (rt_comm_init / rt_gather_frame)", "gather_every": args.gather_every}
+
     def make_renderer(count):
         # work counters (reference units) come from the reference-shaped megakernel; the timed run uses `pipeline`
         r = rt.Renderer(device=local_rank, rank=rank, world_size=world,
@@ -136,7 +141,22 @@ def main():
         rc.close()
 
         ren = make_renderer(False)
-        gatherer = FrameGatherer(ren) if world > 1 else None
+        gatherer = None
+        if world > 1:
+            # the exchange runs inside the library (rt_comm_init / rt_gather_frame: RCCL behind the C ABI).  If its communicator
+            # cannot be brought up on this node the run falls back to the same exchange issued through torch.distributed -- on
+            # every rank alike -- and says so in the JSON line.
+            ok = torch.ones(1, device="cuda")
+            if args.gather == "native":
+                try:
+                    gatherer = NativeGatherer(ren, gather_every=args.gather_every)
+                except Exception as e:   # noqa: BLE001
+                    gather_path["error"] = repr(e)[:300]
+                    ok.zero_()
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if args.gather != "native" or ok.item() == 0:
+                gatherer = FrameGatherer(ren)
+                gather_path["path"] = "torch.distributed (RCCL) on the library's device pointers"
         # setup, not a step: every frame lane (3-4 streams with their own ray-queue arenas) allocates on its first frame; do that
         # before the W warm-up steps so that a small W cannot push a multi-GB hipMalloc into the timed region
         for f in range(5):
@@ -151,7 +171,7 @@ def main():
         def step(f):
             ren.render_frame(frames_u[f])
             if gatherer:
-                gatherer.gather()      # one RCCL gather of COLOR0 to rank 0 + un-tiling kernel, on the renderer's stream
+                gatherer.gather()      # RCCL gather of COLOR0 to rank 0 + un-tiling kernel (every --gather-every-th frame), on the frame's stream
 
         for f in range(warmup):
             step(f)
@@ -316,6 +336,7 @@ def main():
                                + ("procedural bunny stand-in (icosphere subdiv %d" % args.subdiv if args.scene == "bunny" else "1M-triangle multi-object scene (")
                                + ", %d tris, median-split BVH), %dx%d, %d spp, GI 1 bounce + AO 4, Sky_01 env, close-up camera (-2,1.5,1.0)" % (tris.shape[0], W, H, SPP),
                    "pipeline": args.pipeline, "tiles": "16x16 round-robin over ranks" if world > 1 else "single GPU",
+                   "gather": gather_path if world > 1 else None,
                    "rays_per_frame": rays // args.steps, "msample_per_s": npix * SPP * args.steps / res["seconds"] / 1e6,
                    "hit_pixels": res["counters"].hitPixels // args.steps,
                    "rays_traversed_per_frame": res["traced_per_frame"],

@@ -198,8 +198,8 @@ typedef struct RtPresentParams {
 void rt_make_present_params(const RtRenderParams *p, int showMotion, int fbw, int fbh, RtPresentParams *out);
 int rt_present(RtContext *ctx, const RtPresentParams *p, uint8_t *dstRGBA8);
 
-/* Tile-parallel plumbing for the RCCL gather (one process per GPU; the collective itself is
- * issued by the host through torch.distributed / RCCL on these device pointers).
+/* Tile-parallel plumbing for a host that runs the exchange itself (e.g. through torch.distributed on these device pointers;
+ * the library's own RCCL path is rt_comm_init / rt_gather_frame / rt_exchange_history below).
  * Local layout: [localTile][RT_TILE_PIXELS][channels] halfs, localTile = globalTile / worldSize for
  * globalTile % worldSize == rank, globalTile = tileY * tilesX + tileX. */
 int rt_local_target(RtContext *ctx, int which, void **devPtr, size_t *bytes);
@@ -224,6 +224,26 @@ int rt_history_exchanged(RtContext *ctx);
  * blocks each (as filled by the gather of COLOR / MOTION / GPOS / GNRM, rank-major, rt_gather_block_bytes per block). */
 int rt_present_gathered(RtContext *ctx, const RtPresentParams *p, const void *gatheredColor, const void *gatheredMotion,
                         const void *gatheredGPos, const void *gatheredGNrm, uint8_t *dstRGBA8);
+
+/* ---- the exchange itself, owned by the library ("the library owns device memory, streams and the RCCL
+ * communicator"; 8e: gather for a static camera, all-gather of the history for a moving one).  One process per GPU; every call
+ * below is collective over the ranks of the frame (RtDeviceConfig.rank / worldSize) and asynchronous on the stream of the frame
+ * rendered last.  A C++ host needs nothing else to render tile-parallel: csrc/rt_cli.cpp --ranks N.
+ *   rank 0:  rt_comm_unique_id(id)  -> hand the 128 bytes to the other ranks by any means (file, pipe, MPI, torch store)
+ *   all:     rt_comm_init(ctx, id)  -> ncclCommInitRank
+ *   per gathered frame:  rt_render_frame / rt_render_ray; rt_gather_frame(ctx, RT_TARGET_COLOR)   [+ rt_exchange_history]
+ *   rank 0:  rt_read_gathered(ctx, RT_TARGET_COLOR, halfs)   or rt_gathered_frame() for the device pointer
+ * Static camera: a pixel only reads its own history (rt_taa.glsl:86-105), which stays rank-local, so intermediate frames need
+ * not be gathered at all -- call rt_gather_frame every k-th frame (BASELINE configs[4]: once per 32 accumulated frames). */
+#define RT_COMM_ID_BYTES 128
+int rt_comm_unique_id(void *id, size_t bytes);                         /* any process; needs librccl */
+int rt_comm_init(RtContext *ctx, const void *id, size_t bytes);
+int rt_comm_destroy(RtContext *ctx);                                   /* also done by rt_destroy */
+int rt_gather_frame(RtContext *ctx, int which);                        /* worldSize == 1: a device copy + un-tiling, no RCCL */
+int rt_gathered_frame(RtContext *ctx, int which, void **devPtr, size_t *bytes);   /* rank 0: row-major width x height halfs, row 0 = bottom */
+int rt_read_gathered(RtContext *ctx, int which, void *dstHalfs);       /* rank 0: synchronises, copies that frame to the host */
+int rt_present_last_gathered(RtContext *ctx, const RtPresentParams *p, uint8_t *dstRGBA8);   /* rank 0, after rt_gather_frame of all 4 targets */
+int rt_exchange_history(RtContext *ctx);                               /* all-gather of COLOR0 + rt_history_exchanged() */
 
 int rt_get_counters(RtContext *ctx, RtCounters *out);   /* needs countWork; totals since rt_reset_counters */
 int rt_reset_counters(RtContext *ctx);

@@ -26,6 +26,7 @@ RT_FORMAT_F16, RT_FORMAT_F32 = 0, 1
 RT_PIPELINE_AUTO, RT_PIPELINE_MEGAKERNEL, RT_PIPELINE_WAVEFRONT = 0, 1, 2
 TARGET_CHANNELS = {0: 4, 1: 2, 2: 4, 3: 4}
 RT_MAX_STAGES = 12
+RT_COMM_ID_BYTES = 128
 
 f32, i32 = C.c_float, C.c_int32
 
@@ -177,6 +178,14 @@ SIGNATURES = {
     "rt_gather_block_bytes": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]),
     "rt_assemble_gathered": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "rt_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "rt_comm_unique_id": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "rt_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "rt_comm_destroy": (C.c_int, [C.c_void_p]),
+    "rt_gather_frame": (C.c_int, [C.c_void_p, C.c_int]),
+    "rt_gathered_frame": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "rt_read_gathered": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "rt_present_last_gathered": (C.c_int, [C.c_void_p, C.POINTER(RtPresentParams), _U8P]),
+    "rt_exchange_history": (C.c_int, [C.c_void_p]),
     "rt_get_counters": (C.c_int, [C.c_void_p, C.POINTER(RtCounters)]),
     "rt_reset_counters": (C.c_int, [C.c_void_p]),
     "rt_get_scene_info": (C.c_int, [C.c_void_p, C.POINTER(RtSceneInfo)]),
@@ -249,6 +258,15 @@ def lib():
     assert L.rt_sizeof_render_params() == C.sizeof(RtRenderParams), "RtRenderParams layout drifted"
     _lib = L
     return L
+
+
+def comm_unique_id() -> bytes:
+    """ncclGetUniqueId through the library: 128 bytes for rank 0 to hand to every rank's Renderer.comm_init."""
+    buf = C.create_string_buffer(RT_COMM_ID_BYTES)
+    rc = lib().rt_comm_unique_id(buf, RT_COMM_ID_BYTES)
+    if rc != RT_OK:
+        raise RtError(rc, (lib().rt_last_error(None) or b"").decode())
+    return buf.raw
 
 
 def _fp(a):
@@ -527,6 +545,39 @@ class Renderer:
 
     def read_all(self):
         return [self.read_target(i) for i in range(4)]
+
+    # ---- tile-parallel exchange owned by the library (RCCL behind the C ABI)
+    def comm_init(self, comm_id: bytes):
+        """Collective over the ranks of the frame.  comm_id: the 128 bytes rank 0 got from comm_unique_id()."""
+        buf = C.create_string_buffer(bytes(comm_id), RT_COMM_ID_BYTES)
+        self._check(lib().rt_comm_init(self._h, buf, RT_COMM_ID_BYTES))
+
+    def comm_destroy(self):
+        self._check(lib().rt_comm_destroy(self._h))
+
+    def gather_frame(self, which=RT_TARGET_COLOR):
+        """Enqueue the gather of the last frame's target to rank 0 (+ un-tiling there) on that frame's stream."""
+        self._check(lib().rt_gather_frame(self._h, which))
+
+    def gathered_frame_ptr(self, which=RT_TARGET_COLOR):
+        p, n = C.c_void_p(), C.c_size_t()
+        self._check(lib().rt_gathered_frame(self._h, which, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def read_gathered(self, which=RT_TARGET_COLOR) -> np.ndarray:
+        """Rank 0: the frame of the last gather_frame(which) as half bit patterns [H, W, C] (synchronises)."""
+        out = np.zeros((self.height, self.width, TARGET_CHANNELS[which]), np.uint16)
+        self._check(lib().rt_read_gathered(self._h, which, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def present_last_gathered(self, pp: RtPresentParams) -> np.ndarray:
+        out = np.zeros((self.height, self.width, 4), np.uint8)
+        self._check(lib().rt_present_last_gathered(self._h, C.byref(pp), out.ctypes.data_as(_U8P)))
+        return out
+
+    def exchange_history(self):
+        """All-gather of the last frame's COLOR0 blocks so that the next frame may reproject across tiles (moving camera)."""
+        self._check(lib().rt_exchange_history(self._h))
 
     def local_target(self, which):
         p, n = C.c_void_p(), C.c_size_t()

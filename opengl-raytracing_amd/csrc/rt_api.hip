@@ -11,6 +11,9 @@
 #include <string>
 #include <vector>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and prototypes only: RCCL is bound at run time (rccl_api below), single-GPU users never load it
+
 #include "../../include/rt_mi355.h"
 #include "rt_frame.hpp"
 #include "rt_wave.hpp"
@@ -47,8 +50,10 @@ struct RtContext {
     FrameGeom g{};
     bool sized = false;
     uint2 *dColor[RT_MAX_LANES] = {};   // COLOR0 ring: frame f writes [f % nLanes], reads [(f-1) % nLanes]
-    uint32_t *dMotion = nullptr;
-    uint2 *dGPos = nullptr, *dGNrm = nullptr;
+    // motion / position / normal are ringed like COLOR0: a gather (or any other reader) of frame f's targets runs on lane f's
+    // stream and must not see frame f+1's stores, which run on another stream
+    uint32_t *dMotion[RT_MAX_LANES] = {};
+    uint2 *dGPos[RT_MAX_LANES] = {}, *dGNrm[RT_MAX_LANES] = {};
     size_t nSlots = 0;
     int frameIndex = 0, writeIdx = 0;     // include/render/accum.h:125-138
     bool haveFrameState = false;
@@ -58,6 +63,11 @@ struct RtContext {
     void *dStaging = nullptr;
     size_t stagingBytes = 0;
     RtWave *wave[RT_MAX_LANES] = {};
+    // tile-parallel exchange owned by the library (rt_comm.cpp): RCCL communicator + per-lane gather buffers on the gathering rank
+    void *comm = nullptr;                               // ncclComm_t
+    void *dGathered[RT_MAX_LANES][4] = {};              // [lane][target]: worldSize blocks, rank-major
+    void *dAssembled[RT_MAX_LANES][4] = {};             // [lane][target]: row-major frame of halfs
+    int gatheredLane[4] = {-1, -1, -1, -1};             // lane whose frame rt_gather_frame(which) gathered last
     // timing
     bool timing = false;
     std::vector<StageEvent> pending;
@@ -201,13 +211,26 @@ DevScene make_dev_scene(const RtContext *c) {
     return s;
 }
 
+void free_gather_buffers(RtContext *c) {
+    for (int l = 0; l < RT_MAX_LANES; ++l)
+        for (int w = 0; w < 4; ++w) {
+            if (c->dGathered[l][w]) (void)hipFree(c->dGathered[l][w]);
+            if (c->dAssembled[l][w]) (void)hipFree(c->dAssembled[l][w]);
+            c->dGathered[l][w] = c->dAssembled[l][w] = nullptr;
+        }
+    for (int w = 0; w < 4; ++w) c->gatheredLane[w] = -1;
+}
+
 void free_targets(RtContext *c) {
     for (int i = 0; i < RT_MAX_LANES; ++i) { if (c->dColor[i]) (void)hipFree(c->dColor[i]); c->dColor[i] = nullptr; }
     for (int i = 0; i < RT_MAX_LANES; ++i) { if (c->dHistAll[i]) (void)hipFree(c->dHistAll[i]); c->dHistAll[i] = nullptr; c->histExchanged[i] = false; }
-    if (c->dMotion) (void)hipFree(c->dMotion);
-    if (c->dGPos) (void)hipFree(c->dGPos);
-    if (c->dGNrm) (void)hipFree(c->dGNrm);
-    c->dMotion = nullptr; c->dGPos = c->dGNrm = nullptr;
+    for (int i = 0; i < RT_MAX_LANES; ++i) {
+        if (c->dMotion[i]) (void)hipFree(c->dMotion[i]);
+        if (c->dGPos[i]) (void)hipFree(c->dGPos[i]);
+        if (c->dGNrm[i]) (void)hipFree(c->dGNrm[i]);
+        c->dMotion[i] = nullptr; c->dGPos[i] = c->dGNrm[i] = nullptr;
+    }
+    free_gather_buffers(c);
     c->sized = false;
 }
 
@@ -220,12 +243,14 @@ int ensure_staging(RtContext *c, size_t bytes) {
     return RT_OK;
 }
 
+int last_lane(const RtContext *c) { return (c->writeIdx + c->nLanes - 1) % c->nLanes; }   // lane of the frame rendered last
 void *target_ptr(RtContext *c, int which, int &channels) {
+    const int l = last_lane(c);
     switch (which) {
-        case RT_TARGET_COLOR: channels = 4; return c->dColor[(c->writeIdx + c->nLanes - 1) % c->nLanes];   // the frame written last
-        case RT_TARGET_MOTION: channels = 2; return c->dMotion;
-        case RT_TARGET_GPOS: channels = 4; return c->dGPos;
-        case RT_TARGET_GNRM: channels = 4; return c->dGNrm;
+        case RT_TARGET_COLOR: channels = 4; return c->dColor[l];
+        case RT_TARGET_MOTION: channels = 2; return c->dMotion[l];
+        case RT_TARGET_GPOS: channels = 4; return c->dGPos[l];
+        case RT_TARGET_GNRM: channels = 4; return c->dGNrm[l];
         default: channels = 0; return nullptr;
     }
 }
@@ -321,6 +346,7 @@ void rt_destroy(RtContext *c) {
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
     (void)sync_all(c);
+    (void)rt_comm_destroy(c);
     free_targets(c);
     for (int i = 0; i < RT_MAX_LANES; ++i) { if (c->wave[i]) rt_wave_destroy(c->wave[i]); if (c->dFrame[i]) (void)hipFree(c->dFrame[i]); if (c->evDone[i]) (void)hipEventDestroy(c->evDone[i]); }
     for (int i = 1; i < RT_MAX_LANES; ++i) if (c->lanes[i]) (void)hipStreamDestroy(c->lanes[i]);
@@ -555,9 +581,11 @@ int rt_resize(RtContext *c, int w, int h) {
     const size_t maxLocal = (size_t)(g.nTiles + g.world - 1) / g.world;
     c->nSlots = std::max<size_t>(maxLocal, 1) * RT_TILE_PIXELS;
     for (int i = 0; i < c->nLanes; ++i) HIP_TRY(c, hipMalloc(&c->dColor[i], c->nSlots * 8));
-    HIP_TRY(c, hipMalloc(&c->dMotion, c->nSlots * 4));
-    HIP_TRY(c, hipMalloc(&c->dGPos, c->nSlots * 8));
-    HIP_TRY(c, hipMalloc(&c->dGNrm, c->nSlots * 8));
+    for (int i = 0; i < c->nLanes; ++i) {
+        HIP_TRY(c, hipMalloc(&c->dMotion[i], c->nSlots * 4));
+        HIP_TRY(c, hipMalloc(&c->dGPos[i], c->nSlots * 8));
+        HIP_TRY(c, hipMalloc(&c->dGNrm[i], c->nSlots * 8));
+    }
     c->sized = true;
     c->haveFrameState = false;
     return rt_reset_accum(c);
@@ -572,9 +600,12 @@ int rt_reset_accum(RtContext *c) {
     c->writeIdx = 0;
     for (int i = 0; i < RT_MAX_LANES; ++i) c->histExchanged[i] = false;
     for (int i = 0; i < c->nLanes; ++i) HIP_TRY(c, hipMemsetAsync(c->dColor[i], 0, c->nSlots * 8, c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->dMotion, 0, c->nSlots * 4, c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->dGPos, 0, c->nSlots * 8, c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->dGNrm, 0, c->nSlots * 8, c->stream));
+    for (int i = 0; i < c->nLanes; ++i) {
+        HIP_TRY(c, hipMemsetAsync(c->dMotion[i], 0, c->nSlots * 4, c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->dGPos[i], 0, c->nSlots * 8, c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->dGNrm[i], 0, c->nSlots * 8, c->stream));
+    }
+    for (int w = 0; w < 4; ++w) c->gatheredLane[w] = -1;
     return RT_OK;
 }
 
@@ -613,7 +644,7 @@ int rt_render_frame(RtContext *c, const RtUniforms *uIn) {
     tg.prevAll = needAll ? (const uint2 *)c->dHistAll[prevLane] : nullptr;
     tg.blockSlots = (int)c->nSlots;
     c->histExchanged[lane] = false;   // this lane's exchange buffer belongs to the frame that is about to be rendered
-    tg.motion = c->dMotion; tg.gpos = c->dGPos; tg.gnrm = c->dGNrm;
+    tg.motion = c->dMotion[lane]; tg.gpos = c->dGPos[lane]; tg.gnrm = c->dGNrm[lane];
     const bool count = c->cfg.countWork != 0;
     int pipeline = c->cfg.pipeline;
     if (pipeline == RT_PIPELINE_AUTO) pipeline = (fr.u.useBVH == 1 && fr.sc.hasBVH && !count) ? RT_PIPELINE_WAVEFRONT : RT_PIPELINE_MEGAKERNEL;
@@ -709,7 +740,7 @@ int rt_present(RtContext *c, const RtPresentParams *p, uint8_t *dst) {
     int rc = ensure_staging(c, bytes);
     if (rc != RT_OK) return rc;
     rt_stage_begin(c, 11);
-    HIP_TRY(c, rtl::launch_present(c->stream, c->g, c->dColor[(c->writeIdx + c->nLanes - 1) % c->nLanes], c->dMotion, c->dGPos, c->dGNrm, *p, (uint32_t *)c->dStaging));
+    HIP_TRY(c, rtl::launch_present(c->stream, c->g, c->dColor[last_lane(c)], c->dMotion[last_lane(c)], c->dGPos[last_lane(c)], c->dGNrm[last_lane(c)], *p, (uint32_t *)c->dStaging));
     rt_stage_end(c, 11, 1);
     HIP_TRY(c, hipMemcpyAsync(dst, c->dStaging, bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, sync_all(c));
@@ -902,6 +933,193 @@ int rt_debug_trace(RtContext *c, int kind, const float *origins, const float *di
     HIP_TRY(c, hipMemcpy(out7, dOut, (size_t)n * 28, hipMemcpyDeviceToHost));
     (void)hipFree(dO); (void)hipFree(dD); (void)hipFree(dT); (void)hipFree(dOut);
     return RT_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// Tile-parallel exchange over RCCL, owned by the library.  librccl is half a gigabyte and only multi-GPU
+// runs need it, so it is bound on first use: an already loaded copy (e.g. the one a PyTorch wheel brought into the process) is
+// reused by SONAME, otherwise librccl.so.1 is loaded from the ROCm installation.
+namespace {
+struct RcclApi {
+    decltype(&ncclGetUniqueId) getUniqueId = nullptr;
+    decltype(&ncclCommInitRank) commInitRank = nullptr;
+    decltype(&ncclCommDestroy) commDestroy = nullptr;
+    decltype(&ncclGroupStart) groupStart = nullptr;
+    decltype(&ncclGroupEnd) groupEnd = nullptr;
+    decltype(&ncclSend) send = nullptr;
+    decltype(&ncclRecv) recv = nullptr;
+    decltype(&ncclAllGather) allGather = nullptr;
+    decltype(&ncclGetErrorString) errorString = nullptr;
+    std::string err;
+    bool ok = false;
+};
+RcclApi &rccl_api() {
+    static RcclApi a;
+    if (a.ok || !a.err.empty()) return a;
+    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) { a.err = std::string("librccl.so.1 could not be loaded: ") + (dlerror() ? dlerror() : "?"); return a; }
+#define RT_BIND(field, name) do { a.field = (decltype(a.field))dlsym(h, #name); if (!a.field) { a.err = "librccl lacks " #name; return a; } } while (0)
+    RT_BIND(getUniqueId, ncclGetUniqueId); RT_BIND(commInitRank, ncclCommInitRank); RT_BIND(commDestroy, ncclCommDestroy);
+    RT_BIND(groupStart, ncclGroupStart); RT_BIND(groupEnd, ncclGroupEnd); RT_BIND(send, ncclSend); RT_BIND(recv, ncclRecv);
+    RT_BIND(allGather, ncclAllGather); RT_BIND(errorString, ncclGetErrorString);
+#undef RT_BIND
+    a.ok = true;
+    return a;
+}
+#define NCCL_TRY(c, expr)                                                                                           \
+    do {                                                                                                            \
+        ncclResult_t r_ = (expr);                                                                                   \
+        if (r_ != ncclSuccess) return fail((c), RT_ERR_HIP, "%s failed: %s", #expr, rccl_api().errorString(r_));     \
+    } while (0)
+void *lane_target(RtContext *c, int lane, int which, int &ch) {
+    switch (which) {
+        case RT_TARGET_COLOR: ch = 4; return c->dColor[lane];
+        case RT_TARGET_MOTION: ch = 2; return c->dMotion[lane];
+        case RT_TARGET_GPOS: ch = 4; return c->dGPos[lane];
+        case RT_TARGET_GNRM: ch = 4; return c->dGNrm[lane];
+        default: ch = 0; return nullptr;
+    }
+}
+}  // namespace
+
+extern "C" {
+
+int rt_comm_unique_id(void *id, size_t bytes) {
+    if (!id || bytes < RT_COMM_ID_BYTES) return fail(nullptr, RT_ERR_INVALID, "rt_comm_unique_id: need %d bytes", RT_COMM_ID_BYTES);
+    RcclApi &a = rccl_api();
+    if (!a.ok) return fail(nullptr, RT_ERR_UNSUPPORTED, "rt_comm_unique_id: %s", a.err.c_str());
+    static_assert(sizeof(ncclUniqueId) == RT_COMM_ID_BYTES, "RT_COMM_ID_BYTES");
+    ncclUniqueId u;
+    ncclResult_t r = a.getUniqueId(&u);
+    if (r != ncclSuccess) return fail(nullptr, RT_ERR_HIP, "ncclGetUniqueId: %s", a.errorString(r));
+    std::memcpy(id, &u, sizeof u);
+    return RT_OK;
+}
+
+int rt_comm_init(RtContext *c, const void *id, size_t bytes) {
+    if (!c || !id || bytes < RT_COMM_ID_BYTES) return RT_ERR_INVALID;
+    if (c->comm) return fail(c, RT_ERR_STATE, "rt_comm_init: the context already has a communicator");
+    RcclApi &a = rccl_api();
+    if (!a.ok) return fail(c, RT_ERR_UNSUPPORTED, "rt_comm_init: %s", a.err.c_str());
+    (void)hipSetDevice(c->cfg.device);
+    HIP_TRY(c, sync_all(c));
+    ncclUniqueId u;
+    std::memcpy(&u, id, sizeof u);
+    ncclComm_t comm = nullptr;
+    NCCL_TRY(c, a.commInitRank(&comm, c->cfg.worldSize, u, c->cfg.rank));   // collective over all ranks of the frame
+    c->comm = (void *)comm;
+    return RT_OK;
+}
+
+int rt_comm_destroy(RtContext *c) {
+    if (!c) return RT_ERR_INVALID;
+    if (!c->comm) return RT_OK;
+    (void)hipSetDevice(c->cfg.device);
+    (void)sync_all(c);
+    ncclResult_t r = rccl_api().commDestroy((ncclComm_t)c->comm);
+    c->comm = nullptr;
+    if (r != ncclSuccess) return fail(c, RT_ERR_HIP, "ncclCommDestroy: %s", rccl_api().errorString(r));
+    return RT_OK;
+}
+
+// One exchange per gathered frame: every rank sends the block of its tiles to rank 0 -- grouped point-to-point
+// transfers, so the root's inbound xGMI links run in parallel and nothing is reduced -- and rank 0 un-tiles the blocks into a
+// row-major frame.  Everything is enqueued on the lane (stream) of the frame rendered last and uses that lane's own buffers, so
+// gathers of consecutive frames overlap like the frames themselves and never share a buffer.
+int rt_gather_frame(RtContext *c, int which) {
+    if (!c) return RT_ERR_INVALID;
+    if (!c->sized) return fail(c, RT_ERR_STATE, "rt_gather_frame before rt_resize");
+    if (c->frameIndex == 0) return fail(c, RT_ERR_STATE, "rt_gather_frame before the first frame");
+    if (c->g.world > 1 && !c->comm) return fail(c, RT_ERR_STATE, "rt_gather_frame on a tile-parallel context without rt_comm_init");
+    (void)hipSetDevice(c->cfg.device);
+    const int lane = last_lane(c);
+    int ch;
+    void *local = lane_target(c, lane, which, ch);
+    if (!local) return fail(c, RT_ERR_INVALID, "rt_gather_frame: which=%d", which);
+    const size_t block = c->nSlots * (size_t)ch * 2;
+    hipStream_t st = c->lanes[lane];
+    const bool root = c->g.rank == 0;
+    if (root) {
+        if (!c->dGathered[lane][which]) HIP_TRY(c, hipMalloc(&c->dGathered[lane][which], block * (size_t)c->g.world));
+        if (!c->dAssembled[lane][which]) HIP_TRY(c, hipMalloc(&c->dAssembled[lane][which], (size_t)c->g.W * c->g.H * ch * 2));
+        HIP_TRY(c, hipMemcpyAsync(c->dGathered[lane][which], local, block, hipMemcpyDeviceToDevice, st));
+    }
+    if (c->g.world > 1) {
+        RcclApi &a = rccl_api();
+        ncclComm_t comm = (ncclComm_t)c->comm;
+        NCCL_TRY(c, a.groupStart());
+        if (root) {
+            for (int r = 1; r < c->g.world; ++r)
+                NCCL_TRY(c, a.recv((char *)c->dGathered[lane][which] + (size_t)r * block, block, ncclUint8, r, comm, st));
+        } else {
+            NCCL_TRY(c, a.send(local, block, ncclUint8, 0, comm, st));
+        }
+        NCCL_TRY(c, a.groupEnd());
+    }
+    if (root) {
+        const size_t n = (size_t)c->g.W * c->g.H;
+        rt_stage_begin(c, 10, st);
+        hipLaunchKernelGGL(k_assemble, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const void *)c->dGathered[lane][which],
+                           c->dAssembled[lane][which], c->g, ch, block);
+        rt_stage_end(c, 10, 1, st);
+        HIP_TRY(c, hipGetLastError());
+    }
+    c->gatheredLane[which] = lane;
+    return RT_OK;
+}
+
+int rt_gathered_frame(RtContext *c, int which, void **devPtr, size_t *bytes) {
+    if (!c || !devPtr || !bytes || which < 0 || which > 3) return RT_ERR_INVALID;
+    if (c->g.rank != 0) return fail(c, RT_ERR_STATE, "rt_gathered_frame: only rank 0 holds the gathered frame");
+    const int lane = c->gatheredLane[which];
+    if (lane < 0 || !c->dAssembled[lane][which]) return fail(c, RT_ERR_STATE, "rt_gathered_frame: no rt_gather_frame(%d) since the last reset", which);
+    *devPtr = c->dAssembled[lane][which];
+    *bytes = (size_t)c->g.W * c->g.H * (which == RT_TARGET_MOTION ? 2 : 4) * 2;
+    return RT_OK;
+}
+
+int rt_read_gathered(RtContext *c, int which, void *dstHalfs) {
+    if (!c || !dstHalfs) return RT_ERR_INVALID;
+    void *p;
+    size_t n;
+    int rc = rt_gathered_frame(c, which, &p, &n);
+    if (rc != RT_OK) return rc;
+    (void)hipSetDevice(c->cfg.device);
+    HIP_TRY(c, sync_all(c));
+    HIP_TRY(c, hipMemcpy(dstHalfs, p, n, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_present_last_gathered(RtContext *c, const RtPresentParams *p, uint8_t *dst) {
+    if (!c || !p || !dst) return RT_ERR_INVALID;
+    if (c->g.rank != 0) return fail(c, RT_ERR_STATE, "rt_present_last_gathered: only rank 0 holds the gathered targets");
+    const int lane = c->gatheredLane[0];
+    for (int w = 0; w < 4; ++w)
+        if (c->gatheredLane[w] < 0 || c->gatheredLane[w] != lane || !c->dGathered[lane][w])
+            return fail(c, RT_ERR_STATE, "rt_present_last_gathered: gather all four targets of the same frame first (rt_gather_frame 0..3)");
+    return rt_present_gathered(c, p, c->dGathered[lane][0], c->dGathered[lane][1], c->dGathered[lane][2], c->dGathered[lane][3], dst);
+}
+
+// Moving camera on a tile-parallel frame: every rank needs the whole previous COLOR0 (rt_taa.glsl:116-179 reads it at arbitrary
+// pixels) -> one all-gather of the ranks' blocks into this lane's exchange buffer, then the event the next frame's resolve waits on.
+int rt_exchange_history(RtContext *c) {
+    if (!c) return RT_ERR_INVALID;
+    if (!c->sized) return fail(c, RT_ERR_STATE, "rt_exchange_history before rt_resize");
+    if (c->g.world > 1 && !c->comm) return fail(c, RT_ERR_STATE, "rt_exchange_history on a tile-parallel context without rt_comm_init");
+    void *buf;
+    size_t bytes;
+    int rc = rt_history_exchange_buffer(c, &buf, &bytes);
+    if (rc != RT_OK) return rc;
+    const int lane = last_lane(c);
+    const size_t block = c->nSlots * 8;
+    if (c->g.world > 1) NCCL_TRY(c, rccl_api().allGather(c->dColor[lane], buf, block, ncclUint8, (ncclComm_t)c->comm, c->lanes[lane]));
+    else HIP_TRY(c, hipMemcpyAsync(buf, c->dColor[lane], block, hipMemcpyDeviceToDevice, c->lanes[lane]));
+    return rt_history_exchanged(c);
 }
 
 }  // extern "C"

@@ -6,11 +6,21 @@
 //   rt_cli --obj models/bunny.obj --env cubemaps/Sky_16.png --size 1920x1080 --spp 4 --frames 32 --bvh --out frame
 // Several --obj files are merged into one triangle soup before build_bvh (a multi-object scene, BASELINE config 5);
 // --dump-targets also writes the four render targets of the last frame as little-endian PFM (float, bottom row first).
+//
+// Tile-parallel: --ranks N forks N processes BEFORE anything touches a GPU (rank r drives --devices[r], default device r); each
+// renders the 16x16 tiles with tile % N == r, rank 0 creates the RCCL id (rt_comm_unique_id) and hands it over through a file,
+// all call rt_comm_init, and every --gather-every k-th frame (and the last one) ends with rt_gather_frame -- for a static camera
+// the accumulation history is tile-local, so frames in between need no exchange at all.  Rank 0 presents from
+// the gathered targets and writes the same files a single-GPU run writes.
+#include <sys/wait.h>
+#include <unistd.h>
+
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstddef>
+#include <algorithm>
 #include <cstring>
 #include <fstream>
 #include <sstream>
@@ -87,6 +97,19 @@ static bool set_param(RtRenderParams &p, const std::string &key, const Value &v)
 }
 }  // namespace scenefile
 
+static float half_to_float(uint16_t h) {   // exact widening of an IEEE binary16
+    const uint32_t s = (uint32_t)(h >> 15) << 31, e = (h >> 10) & 31u, m = h & 1023u;
+    uint32_t bits;
+    if (e == 0) {
+        if (m == 0) bits = s;
+        else { int sh = 0; uint32_t mm = m; while (!(mm & 1024u)) { mm <<= 1; ++sh; } bits = s | (uint32_t)(113 - sh) << 23 | (mm & 1023u) << 13; }
+    } else if (e == 31) bits = s | 0x7f800000u | m << 13;
+    else bits = s | (e + 112u) << 23 | m << 13;
+    float f;
+    std::memcpy(&f, &bits, 4);
+    return f;
+}
+
 static void die(RtContext *c, const char *what, int rc) {
     std::fprintf(stderr, "rt_cli: %s failed (%d): %s\n", what, rc, rt_last_error(c));
     std::exit(1);
@@ -98,6 +121,8 @@ int main(int argc, char **argv) {
     bool dumpTargets = false;
     float dt = 1.0f / 60.0f;   // seconds per frame for the point-light orbit
     int W = 1920, H = 1080, frames = 1, device = 0, useBVH = 0, showMotion = 0;
+    int ranks = 0, gatherEvery = 1;          // ranks 0 = plain single-process run without a communicator
+    std::vector<int> devices;
     RtRenderParams params;
     rt_default_render_params(&params);
     RtCamera cam;
@@ -148,6 +173,9 @@ int main(int argc, char **argv) {
         else if (a == "--spp") params.sppPerFrame = std::atoi(next());
         else if (a == "--frames") frames = std::atoi(next());
         else if (a == "--device") device = std::atoi(next());
+        else if (a == "--ranks") ranks = std::atoi(next());
+        else if (a == "--gather-every") gatherEvery = std::max(1, std::atoi(next()));
+        else if (a == "--devices") { std::stringstream ss(next()); std::string t; while (std::getline(ss, t, ',')) devices.push_back(std::atoi(t.c_str())); }
         else if (a == "--bvh") useBVH = 1;
         else if (a == "--analytic") useBVH = 0;
         else if (a == "--motion") showMotion = 1;
@@ -162,16 +190,65 @@ int main(int argc, char **argv) {
         else if (a == "--aspect") { cam.aspect = (float)std::atof(next()); aspectSet = true; }
         else { std::fprintf(stderr, "usage: rt_cli [--obj f.obj] [--env cross.png] [--size WxH] [--spp n] [--frames n] [--bvh|--analytic] [--motion]\n"
                                     "              [--cam x,y,z,yaw,pitch] [--fov deg] [--aspect a] [--exposure e] [--no-gi --no-ao --no-taa --no-svgf --no-env] [--out prefix]\n"
+                                    "              [--ranks N [--devices d0,d1,..] [--gather-every k]]   tile-parallel over N GPUs, one process each, RCCL gather to rank 0\n"
                                     "              (--obj may be repeated; --dump-targets writes prefix_{color,motion,gpos,gnrm}.pfm; --scene file.json sets any of\n"
                                     "               the above and every RenderParams field by name)\n"); return a == "--help" ? 0 : 2; }
     }
     if (!aspectSet) cam.aspect = (float)W / (float)H;
 
+    // ---- tile-parallel: one fresh process per GPU, forked before any GPU call (nothing above this line touches HIP)
+    int rank = 0, world = 1;
+    const std::string idFile = out + ".rccl_id";
+    if (ranks > 0) {
+        world = ranks;
+        if (!devices.empty() && (int)devices.size() != ranks) { std::fprintf(stderr, "rt_cli: --devices needs %d entries\n", ranks); return 2; }
+        std::remove(idFile.c_str());
+        std::vector<pid_t> kids;
+        bool child = false;
+        for (int r = 0; r < ranks; ++r) {
+            pid_t pid = fork();
+            if (pid < 0) { std::perror("rt_cli: fork"); return 1; }
+            if (pid == 0) { rank = r; child = true; break; }
+            kids.push_back(pid);
+        }
+        if (!child) {
+            int bad = 0;
+            for (pid_t k : kids) { int st = 0; if (waitpid(k, &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) ++bad; }
+            std::remove(idFile.c_str());
+            if (bad) std::fprintf(stderr, "rt_cli: %d of %d ranks failed\n", bad, ranks);
+            return bad ? 1 : 0;
+        }
+        device = devices.empty() ? rank : devices[(size_t)rank];
+    }
+    const bool root = rank == 0;
+
     RtDeviceConfig cfg{};
-    cfg.device = device; cfg.rank = 0; cfg.worldSize = 1; cfg.pipeline = RT_PIPELINE_AUTO;
+    cfg.device = device; cfg.rank = rank; cfg.worldSize = world; cfg.pipeline = RT_PIPELINE_AUTO;
     RtContext *ctx = nullptr;
     int rc = rt_create(&cfg, &ctx);
     if (rc != RT_OK) die(nullptr, "rt_create", rc);
+    if (ranks > 0) {
+        unsigned char id[RT_COMM_ID_BYTES];
+        if (root) {
+            if ((rc = rt_comm_unique_id(id, sizeof id)) != RT_OK) die(nullptr, "rt_comm_unique_id", rc);
+            const std::string tmp = idFile + ".tmp";
+            FILE *fp = std::fopen(tmp.c_str(), "wb");
+            if (!fp || std::fwrite(id, 1, sizeof id, fp) != sizeof id) { std::fprintf(stderr, "rt_cli: cannot write %s\n", tmp.c_str()); return 1; }
+            std::fclose(fp);
+            std::rename(tmp.c_str(), idFile.c_str());          // atomic: readers see all 128 bytes or no file
+        } else {
+            bool got = false;
+            for (int tries = 0; tries < 1200 && !got; ++tries) {   // up to 2 minutes
+                FILE *fp = std::fopen(idFile.c_str(), "rb");
+                if (fp) { got = std::fread(id, 1, sizeof id, fp) == sizeof id; std::fclose(fp); }
+                if (!got) usleep(100 * 1000);
+            }
+            if (!got) { std::fprintf(stderr, "rt_cli: rank %d never saw %s\n", rank, idFile.c_str()); return 1; }
+        }
+        if ((rc = rt_comm_init(ctx, id, sizeof id)) != RT_OK) die(ctx, "rt_comm_init", rc);
+        if (root) std::printf("[RCCL] %d ranks, communicator up\n", world);
+    }
+#define RT_SAY(...) do { if (root) std::printf(__VA_ARGS__); } while (0)
 
     if (!objs.empty()) {
         float M[16];
@@ -184,14 +261,14 @@ int main(int argc, char **argv) {
             tris9.resize(at + (size_t)(ni / 3) * 9);
             const int nt = rt_gather_triangles(pos, idx, ni, M, tris9.data() + at);
             tris9.resize(at + (size_t)nt * 9);
-            std::printf("[OBJ] %s: %d vertices, %d triangles\n", obj.c_str(), nv, nt);
+            RT_SAY("[OBJ] %s: %d vertices, %d triangles\n", obj.c_str(), nv, nt);
             rt_free(pos); rt_free(idx);
         }
         const int nt = (int)(tris9.size() / 9);
         std::vector<float> nodes12((size_t)nt * 24 + 12), tris12((size_t)nt * 12 + 12);
         const int nn = rt_build_bvh(tris9.data(), nt, nodes12.data(), tris12.data());
         if ((rc = rt_upload_bvh(ctx, nodes12.data(), nn, tris12.data(), nt)) != RT_OK) die(ctx, "rt_upload_bvh", rc);
-        std::printf("[BVH] %d triangles, %d nodes\n", nt, nn);
+        RT_SAY("[BVH] %d triangles, %d nodes\n", nt, nn);
     }
     if (!env.empty()) {
         uint8_t *px = nullptr; int w = 0, h = 0, ch = 0;
@@ -201,7 +278,7 @@ int main(int argc, char **argv) {
         rt_free(px);
         if (n == 0) { std::fprintf(stderr, "[ENV] %s is not a 4x3 cross, keeping the dummy cube map\n", env.c_str()); }   // application.cpp:294-304
         else if ((rc = rt_upload_env(ctx, faces.data(), n, ch)) != RT_OK) die(ctx, "rt_upload_env", rc);
-        else std::printf("[ENV] %s: 6 x %dx%d\n", env.c_str(), n, n);
+        else RT_SAY("[ENV] %s: 6 x %dx%d\n", env.c_str(), n, n);
     }
     if ((rc = rt_resize(ctx, W, H)) != RT_OK) die(ctx, "rt_resize", rc);
 
@@ -216,16 +293,25 @@ int main(int argc, char **argv) {
         if ((rc = rt_render_ray(ctx, &params, &cam, useBVH, showMotion, nullptr, nullptr)) != RT_OK) die(ctx, "rt_render_ray", rc);
         // an orbiting light is dynamic geometry for the accumulation: the history is invalid after every frame (application.cpp:538-553)
         const bool lightMoving = params.pointLightOrbitEnabled != 0 && std::fabs(params.pointLightOrbitSpeed) > 1e-5f && params.pointLightOrbitRadius > 0.0f;
+        // tile-parallel: COLOR0 to rank 0 every gatherEvery-th frame (what an interactive viewer would show) -- frames in between
+        // need no exchange, the history a static camera reads is tile-local
+        if (ranks > 0 && ((f + 1) % gatherEvery == 0 || f + 1 == frames) && (rc = rt_gather_frame(ctx, RT_TARGET_COLOR)) != RT_OK) die(ctx, "rt_gather_frame", rc);
         if (lightMoving && f + 1 < frames && (rc = rt_reset_accum(ctx)) != RT_OK) die(ctx, "rt_reset_accum", rc);
     }
     rt_synchronize(ctx);
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    std::printf("[ACCUM] %d frame(s) %dx%d spp=%d in %.2f ms (%.2f ms/frame)\n", frames, W, H, params.sppPerFrame, ms, ms / (frames > 0 ? frames : 1));
+    RT_SAY("[ACCUM] %d frame(s) %dx%d spp=%d in %.2f ms (%.2f ms/frame)%s\n", frames, W, H, params.sppPerFrame, ms, ms / (frames > 0 ? frames : 1),
+           ranks > 0 ? ", tile-parallel incl. the gathers" : "");
 
     RtPresentParams pp;
     rt_make_present_params(&params, showMotion, W, H, &pp);
     std::vector<uint8_t> rgba((size_t)W * H * 4);
-    if ((rc = rt_present(ctx, &pp, rgba.data())) != RT_OK) die(ctx, "rt_present", rc);
+    if (ranks > 0) {
+        // the 7x7 present filter crosses tiles: all four targets of the last frame go to rank 0, which filters from the gathered blocks
+        for (int t = 1; t < 4; ++t) if ((rc = rt_gather_frame(ctx, t)) != RT_OK) die(ctx, "rt_gather_frame", rc);
+        if (!root) { rt_synchronize(ctx); rt_destroy(ctx); return 0; }
+        if ((rc = rt_present_last_gathered(ctx, &pp, rgba.data())) != RT_OK) die(ctx, "rt_present_last_gathered", rc);
+    } else if ((rc = rt_present(ctx, &pp, rgba.data())) != RT_OK) die(ctx, "rt_present", rc);
     const std::string png = out + ".png";
     if ((rc = rt_save_png(png.c_str(), rgba.data(), W, H, 4, /*flipY=*/1)) != RT_OK) die(ctx, "rt_save_png", rc);
     std::printf("[PRESENT] wrote %s\n", png.c_str());
@@ -234,7 +320,11 @@ int main(int argc, char **argv) {
         static const int chans[4] = {4, 2, 4, 4};
         for (int t = 0; t < 4; ++t) {
             std::vector<float> img((size_t)W * H * chans[t]);
-            if ((rc = rt_read_target(ctx, t, img.data(), RT_FORMAT_F32)) != RT_OK) die(ctx, "rt_read_target", rc);
+            if (ranks > 0) {
+                std::vector<uint16_t> halfs(img.size());
+                if ((rc = rt_read_gathered(ctx, t, halfs.data())) != RT_OK) die(ctx, "rt_read_gathered", rc);
+                for (size_t i = 0; i < img.size(); ++i) img[i] = half_to_float(halfs[i]);
+            } else if ((rc = rt_read_target(ctx, t, img.data(), RT_FORMAT_F32)) != RT_OK) die(ctx, "rt_read_target", rc);
             // PFM holds 1 or 3 channels: RGB of COLOR0 / GPOS / GNRM, and motion as (x, y, 0)
             std::vector<float> rgb((size_t)W * H * 3, 0.0f);
             for (size_t i = 0; i < (size_t)W * H; ++i)

@@ -1,4 +1,11 @@
-"""Tile-parallel frame assembly across GPUs: one process per GPU, RCCL through torch.distributed.
+"""Tile-parallel frame assembly across GPUs: one process per GPU.
+
+Two ways to run the exchange:
+* NativeGatherer -- the library's own RCCL communicator behind the C ABI (rt_comm_init / rt_gather_frame /
+  rt_exchange_history); torch.distributed is only used to hand rank 0's 128-byte id to the other ranks.  This is what
+  bench.py and a C++ host (rt_cli --ranks N) use.
+* FrameGatherer  -- the same exchange issued from Python through torch.distributed (RCCL) on the library's device pointers
+  and streams; kept as the independent cross-check of the native path and as bench.py's fall-back.
 
 Each rank renders its 16x16 tiles into tile-major local targets (csrc/rt_frame.hpp).  Per frame the
 only exchange is ONE gather of the chosen target to rank 0 (RCCL lowers it to grouped send/recv
@@ -40,11 +47,19 @@ class FrameGatherer:
         self._streams = {}
         self.block = renderer.gather_block_bytes(which)
         ch = TARGET_CHANNELS[which]
-        self.gathered = self.frame = None
-        if self.rank == 0:
-            self.gathered = torch.empty((self.world, self.block), dtype=torch.uint8, device=self.device)   # bytes: RCCL has no int16
-            self.frame = torch.empty((renderer.height, renderer.width, ch * 2), dtype=torch.uint8, device=self.device)
+        # one (gathered, frame) buffer pair per frame lane = per stream: gathers of consecutive frames run on different,
+        # unordered streams, so a shared pair would let frame f+1's gather overwrite what frame f's un-tiling still reads
+        self._bufs = {}
+        self._ch = ch
+        self.gathered = self.frame = None       # the pair of the most recent gather()
         self._wrapped = {}
+
+    def _pair(self, sp):
+        b = self._bufs.get(sp)
+        if b is None and self.rank == 0:
+            b = self._bufs[sp] = (torch.empty((self.world, self.block), dtype=torch.uint8, device=self.device),   # bytes: RCCL has no int16
+                                  torch.empty((self.ren.height, self.ren.width, self._ch * 2), dtype=torch.uint8, device=self.device))
+        return b if b is not None else (None, None)
 
     def _local(self):
         ptr, nbytes = self.ren.local_target(self.which)     # COLOR0 ping-pongs between two buffers
@@ -60,6 +75,7 @@ class FrameGatherer:
         stream = self._streams.get(sp)
         if stream is None:
             stream = self._streams[sp] = torch.cuda.ExternalStream(sp, device=self.device)
+        self.gathered, self.frame = self._pair(sp)
         with torch.cuda.stream(stream):
             if self.world > 1:
                 dist.gather(loc, list(self.gathered.unbind(0)) if self.rank == 0 else None, dst=0, group=self.group)
@@ -117,3 +133,41 @@ class FrameGatherer:
         torch.cuda.synchronize()
         ch = TARGET_CHANNELS[self.which]
         return self.frame.cpu().numpy().view("<u2").reshape(self.ren.height, self.ren.width, ch)
+
+
+class NativeGatherer:
+    """The exchange through the library's own communicator.  gather_every=k: only every k-th frame is gathered (static camera:
+    the accumulation history is tile-local, rt_taa.glsl:86-105, so the frames in between need no exchange)."""
+
+    def __init__(self, renderer, which=RT_TARGET_COLOR, group=None, exchange_history=False, gather_every=1):
+        from . import comm_unique_id
+        self.ren, self.which, self.exchange_history = renderer, which, exchange_history
+        self.gather_every = max(1, int(gather_every))
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        ids = [comm_unique_id() if self.rank == 0 else None]
+        if self.world > 1:
+            dist.broadcast_object_list(ids, src=0, group=group)      # 128 bytes over the control plane
+        renderer.comm_init(ids[0])
+        self.frames = 0
+
+    def gather(self, force=False):
+        """After render_frame: gather this frame if it is due (or force=True).  Asynchronous."""
+        self.frames += 1
+        if self.exchange_history and self.world > 1:
+            self.ren.exchange_history()
+        if force or self.frames % self.gather_every == 0:
+            self.ren.gather_frame(self.which)
+            return True
+        return False
+
+    def frame_halfs(self):
+        return self.ren.read_gathered(self.which)
+
+    def present(self, present_params):
+        for which in range(4):
+            self.ren.gather_frame(which)
+        if self.rank != 0:
+            self.ren.synchronize()
+            return None
+        return self.ren.present_last_gathered(present_params)

@@ -165,3 +165,24 @@ def test_cli_point_light_orbit_follows_the_main_loop(tmp_path):
                 r.reset_accum()
         want = r.present(p)[::-1]
     assert np.array_equal(rt.load_png(tmp_path / "o.png"), want)
+
+
+@pytest.mark.gpu
+def test_cli_ranks_mode_equals_the_single_process_run(tmp_path):
+    """rt_cli --ranks 1: a forked child per GPU, RCCL id handed over through a file, rt_comm_init, rt_gather_frame every k-th
+    frame, present from the gathered targets, PFM dumps through rt_read_gathered -- byte-identical to the plain run.  (More
+    than one rank needs more than one GPU: RCCL refuses two ranks on one device.)"""
+    W, H, frames = 128, 80, 5
+    v, f = rt.meshgen.bunny_standin(3)
+    obj = tmp_path / "blob.obj"
+    rt.meshgen.write_obj(obj, v, f)
+    base = [str(CLI), "--obj", str(obj), "--env", str(scenes.ASSETS / "Sky_16.png"), "--size", f"{W}x{H}", "--spp", "2", "--frames", str(frames),
+            "--cam", "-2,1.5,1.0,-90,0", "--dump-targets"]
+    a = subprocess.run(base + ["--out", str(tmp_path / "plain")], capture_output=True, text=True, timeout=300)
+    assert a.returncode == 0, a.stdout + a.stderr
+    b = subprocess.run(base + ["--ranks", "1", "--gather-every", "2", "--out", str(tmp_path / "ranks")], capture_output=True, text=True, timeout=300)
+    assert b.returncode == 0, b.stdout + b.stderr
+    assert "[RCCL] 1 ranks, communicator up" in b.stdout and "tile-parallel" in b.stdout
+    for suffix in (".png", "_color.pfm", "_motion.pfm", "_gpos.pfm", "_gnrm.pfm"):
+        assert (tmp_path / f"plain{suffix}").read_bytes() == (tmp_path / f"ranks{suffix}").read_bytes(), suffix
+    assert not (tmp_path / "ranks.rccl_id").exists()

@@ -207,3 +207,65 @@ def test_frame_gatherer_plumbing_on_a_one_rank_rccl_group():
         assert t.item() == 1.5
     finally:
         dist.destroy_process_group()
+
+
+def test_native_rccl_path_on_a_one_rank_communicator():
+    """The library's own exchange (rt_comm_unique_id / rt_comm_init / rt_gather_frame / rt_exchange_history) on a one-rank RCCL
+    communicator: ncclGetUniqueId + ncclCommInitRank run for real, the gather degenerates to the device copy + un-tiling.
+    Frames and gathers are pipelined over all lanes WITHOUT a host sync (every lane owns its gather buffers and its four
+    targets, so frame f+1 must not tear frame f's gathered image), for several pipeline depths."""
+    W, H = 160, 96
+    nodes, tris, faces, p, cam = _scene(W, H)
+    us = [rt.frame_uniforms(p, cam, W, H, f, True, nodes.shape[0], tris.shape[0]) for f in range(12)]
+    with rt.Renderer() as r:
+        _setup(r, nodes, tris, faces, W, H)
+        r.comm_init(rt.comm_unique_id())
+        want = []
+        for u in us:                                   # reference: synchronised reads of the local targets
+            r.render_frame(u)
+            want.append(r.read_all())
+        for depth in (7, 8, 9, 12):
+            r.reset_accum()
+            for u in us[:depth]:
+                r.render_frame(u)
+                for which in range(4):
+                    r.gather_frame(which)              # enqueued behind the frame on its lane; no sync
+                r.exchange_history()
+            for which in range(4):
+                assert np.array_equal(r.read_gathered(which), want[depth - 1][which]), (depth, which)
+            pp = rt.make_present_params(p, False, W, H)
+            assert np.array_equal(r.present_last_gathered(pp), r.present_with(pp))
+        r.comm_destroy()
+        r.comm_init(rt.comm_unique_id())               # a communicator can be replaced
+        with pytest.raises(rt.RtError):
+            r.comm_init(rt.comm_unique_id())
+
+
+def test_native_gatherer_gather_every():
+    from opengl_raytracing_amd.dist_gather import NativeGatherer
+    W, H = 96, 64
+    nodes, tris, faces, p, cam = _scene(W, H)
+    with rt.Renderer() as r:
+        _setup(r, nodes, tris, faces, W, H)
+        g = NativeGatherer(r, gather_every=4)
+        gathered = []
+        for f in range(9):
+            r.render_frame(rt.frame_uniforms(p, cam, W, H, f, True, nodes.shape[0], tris.shape[0]))
+            if g.gather(force=(f == 8)):
+                gathered.append(f)
+                assert np.array_equal(g.frame_halfs(), r.read_target(rt.RT_TARGET_COLOR))
+        assert gathered == [3, 7, 8]
+
+
+def test_tile_parallel_context_needs_a_communicator():
+    W, H = 64, 48
+    nodes, tris, faces, p, cam = _scene(W, H)
+    with rt.Renderer(rank=1, world_size=2) as r:
+        _setup(r, nodes, tris, faces, W, H)
+        with pytest.raises(rt.RtError) as e:
+            r.gather_frame()
+        assert e.value.code == rt.RT_ERR_STATE
+        r.render_frame(rt.frame_uniforms(p, cam, W, H, 0, True, nodes.shape[0], tris.shape[0]))
+        with pytest.raises(rt.RtError) as e:
+            r.gather_frame()
+        assert "rt_comm_init" in str(e.value)
