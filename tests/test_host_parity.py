@@ -127,6 +127,48 @@ def test_png_reader_and_cross_slicing(orc, tmp_path):
         rt.load_png(tmp_path / "junk.png")
 
 
+def test_png_reader_matches_the_references_own_decoder(tmp_path):
+    """oracle/_ref/libstb_ref.so = the reference's vendored include/stb_image.h, compiled from where it lies under /root/reference by
+    `make -C oracle ref` (oracle/stb_ref.c).  stbi_load(path, &w, &h, &n, 0) is the call loadCubeMapFromCross makes
+    (src/render/cubemap.cpp:40): both cube-map crosses of the reference and PNGs of every colour type / filter the product's reader
+    accepts must decode to the same bytes."""
+    import ctypes as C
+    from pathlib import Path
+    from PIL import Image
+    lib = Path(__file__).resolve().parent.parent / "oracle" / "_ref" / "libstb_ref.so"
+    if not lib.exists():
+        if not Path("/root/reference/include/stb_image.h").exists():
+            pytest.skip("oracle/_ref is built from /root/reference, which is not present here")
+        import subprocess
+        subprocess.run(["make", "-C", str(lib.parent.parent), "ref"], check=True, capture_output=True)
+    L = C.CDLL(str(lib))
+    L.stbi_load.restype = C.POINTER(C.c_ubyte)
+    L.stbi_load.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]
+    L.stbi_image_free.argtypes = [C.c_void_p]
+
+    def stb(path):
+        w, h, n = C.c_int(), C.c_int(), C.c_int()
+        p = L.stbi_load(str(path).encode(), C.byref(w), C.byref(h), C.byref(n), 0)
+        assert p, path
+        a = np.ctypeslib.as_array(p, shape=(h.value, w.value, n.value)).copy()
+        L.stbi_image_free(p)
+        return a
+
+    for name in ("Sky_01", "Sky_16"):
+        want = stb(scenes.ASSETS / f"{name}.png")
+        got = rt.load_png(scenes.ASSETS / f"{name}.png")
+        assert want.shape == (1536, 2048, 3) and np.array_equal(got, want), name
+    rng = np.random.default_rng(9)
+    for i, (mode, shape) in enumerate((("RGBA", (31, 17, 4)), ("RGB", (64, 64, 3)), ("L", (5, 9)), ("RGB", (1, 1, 3)))):
+        a = rng.integers(0, 256, size=shape, dtype=np.uint8)
+        if i == 1:
+            a = np.sort(a, axis=1)                      # smooth rows: the encoder picks Sub / Up / Average / Paeth filters
+        Image.fromarray(a, mode).save(tmp_path / f"t{i}.png", optimize=bool(i % 2))
+        want = stb(tmp_path / f"t{i}.png")
+        got = rt.load_png(tmp_path / f"t{i}.png")
+        assert np.array_equal(got.reshape(want.shape), want), (mode, shape)
+
+
 def test_tile_layout_mirror():
     from opengl_raytracing_amd import tiles
     rng = np.random.default_rng(1)
