@@ -23,8 +23,6 @@ using namespace rtd;
 static thread_local std::string g_createError;
 
 #define RT_MAX_LANES 8
-#define RT_TOP4_LEVELS 3   // 1 + 4 + 16 = 21 four-child records (2352 bytes of LDS per workgroup)
-#define RT_TOP2_LEVELS 6   // 63 two-child records (4032 bytes)
 struct StageEvent { int stage; hipEvent_t a, b; };
 
 struct RtContext {
@@ -47,7 +45,6 @@ struct RtContext {
     int envSize = 0;
     int nNodes = 0, nTris = 0, nInner = 0, rootRef = 0, rootRef4 = 0, treeDepth = 0;
     size_t nWide4 = 0, nPairs = 0;   // records in dW4 / dPairs
-    int nTop4 = 0, nTop2 = 0;        // breadth-first prefix of dW4 / dWNodesW kept in LDS by the traversal kernels
     float rootMin[3] = {0, 0, 0}, rootMax[3] = {0, 0, 0};
     // frame state
     FrameGeom g{};
@@ -209,7 +206,6 @@ DevScene make_dev_scene(const RtContext *c) {
     s.rootRef = c->rootRef;
     s.rootRef4 = c->rootRef4;
     s.hasBVH = (c->nNodes > 0 && c->nTris > 0) ? 1 : 0;
-    s.nTop4 = c->nTop4; s.nTop2 = c->nTop2;
     std::memcpy(s.rootMin, c->rootMin, 12);
     std::memcpy(s.rootMax, c->rootMax, 12);
     return s;
@@ -368,41 +364,6 @@ void rt_destroy(RtContext *c) {
     delete c;
 }
 
-// Renumber a node array breadth-first from record 0, so that the top levels of the tree are its leading records (the traversal
-// kernels copy those to LDS: every ray walks them).  rec = floats per record, refAt = float positions of the child references
-// (int bits: >= 0 inner record index, < 0 leaf, RT_NO_CHILD absent).  Returns the number of records in levels < topLevels.
-static int renumber_breadth_first(std::vector<float> &a, int rec, const std::vector<int> &refAt, int topLevels) {
-    const int n = (int)(a.size() / (size_t)rec);
-    if (n == 0) return 0;
-    std::vector<int> order, level, newIdx((size_t)n, -1);
-    order.reserve((size_t)n); level.reserve((size_t)n);
-    order.push_back(0); level.push_back(0); newIdx[0] = 0;
-    for (size_t h = 0; h < order.size(); ++h) {
-        const float *r = &a[(size_t)order[h] * rec];
-        for (int at : refAt) {
-            int ref;
-            std::memcpy(&ref, &r[at], 4);
-            if (ref < 0 || ref == RT_NO_CHILD || ref >= n || newIdx[(size_t)ref] >= 0) continue;
-            newIdx[(size_t)ref] = (int)order.size();
-            order.push_back(ref); level.push_back(level[h] + 1);
-        }
-    }
-    if ((int)order.size() != n) return 0;            // unreachable records (single-leaf tree placeholder): leave the array alone
-    std::vector<float> b(a.size());
-    int top = 0;
-    for (int i = 0; i < n; ++i) {
-        std::memcpy(&b[(size_t)i * rec], &a[(size_t)order[(size_t)i] * rec], (size_t)rec * 4);
-        for (int at : refAt) {
-            int ref;
-            std::memcpy(&ref, &b[(size_t)i * rec + at], 4);
-            if (ref >= 0 && ref != RT_NO_CHILD) { ref = newIdx[(size_t)ref]; std::memcpy(&b[(size_t)i * rec + at], &ref, 4); }
-        }
-        if (level[(size_t)i] < topLevels) top = i + 1;
-    }
-    a.swap(b);
-    return top;
-}
-
 int rt_upload_bvh(RtContext *c, const float *nodes12, int nNodes, const float *tris12, int nTris) {
     if (!c) return RT_ERR_INVALID;
     if (nNodes < 0 || nTris < 0 || (nNodes > 0 && !nodes12) || (nTris > 0 && !tris12)) return fail(c, RT_ERR_INVALID, "rt_upload_bvh: bad arguments");
@@ -547,12 +508,6 @@ int rt_upload_bvh(RtContext *c, const float *nodes12, int nNodes, const float *t
         }
     } else w4.resize(32, 0.0f);
     if (depth > 32) return fail(c, RT_ERR_UNSUPPORTED, "rt_upload_bvh: tree depth %d exceeds the 32-entry traversal stack", depth);
-    // breadth-first numbering of the two wavefront node arrays; the root stays record 0
-    c->nTop4 = c->nTop2 = 0;
-    if (nd[0].count <= 0) {
-        c->nTop4 = renumber_breadth_first(w4, 32, {24, 25, 26, 27}, RT_TOP4_LEVELS);
-        c->nTop2 = renumber_breadth_first(wnW, 16, {3, 7}, RT_TOP2_LEVELS);
-    }
     HIP_TRY(c, hipMalloc(&c->dWNodes, wn.size() * sizeof(float)));
     HIP_TRY(c, hipMalloc(&c->dW4, w4.size() * sizeof(float)));
     HIP_TRY(c, hipMemcpy(c->dW4, w4.data(), w4.size() * sizeof(float), hipMemcpyHostToDevice));

@@ -39,7 +39,6 @@ struct DevScene {
     int rootRefW;
     int hasBVH;
     float rootMin[3], rootMax[3];
-    int nTop4, nTop2;        // leading records of w4 / wnodesW (numbered breadth-first) that the traversal kernels keep in LDS
 };
 
 struct Work {   // RtCounters, per lane

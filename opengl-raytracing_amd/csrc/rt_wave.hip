@@ -318,7 +318,7 @@ RT_DEV uint32_t nth_set(unsigned long long m, uint32_t n) {
 constexpr uint32_t kShards = 64, kShardStride = 32;   // cursor shards per trace launch, uint32 words between them (128 B)
 constexpr uint32_t kHeadWords = kShards * kShardStride;
 
-struct TraceTune { int refillMin; int minSearch; int chunk; int leafb; int skipTraversal; int useTop; };   // skipTraversal: diagnostic (RT_DEBUG_SKIP_TRAVERSAL)
+struct TraceTune { int refillMin; int minSearch; int chunk; int leafb; int skipTraversal; };   // skipTraversal: diagnostic (RT_DEBUG_SKIP_TRAVERSAL)
 
 template <bool ANY> struct StackOf { typedef StackEntry type; };          // closest: {deferred child, its entry distance}
 template <> struct StackOf<true> { typedef uint32_t type; };              // any-hit: the pop-time cull never fires (tMax is constant)
@@ -337,14 +337,6 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
     DevScene sc = fr->sc;   // private copy: scene constants stay in SGPRs instead of being re-read per step
     sc.tris = tris;         // kernel-argument copies: known-global pointers (global_load, not flat_load)
     const float4 *__restrict__ nodes = wnodes;   // 2-wide records for closest-hit, 4-wide records for any-hit
-    // The top of the tree lives in LDS: the node arrays are numbered breadth-first (rt_upload_bvh), every ray walks the first
-    // levels, and a divergent 16-byte LDS read costs a fraction of a trip through the vector L1.  Lanes whose node is one of
-    // these records advance in LDS-only steps (no global round trip) before each global step of the wave.
-    constexpr int TOPN = ANY ? 21 : 63, TOPW = ANY ? 7 : 4, RECW = ANY ? 8 : 4;   // records, 16-byte pieces used / stored per record
-    __shared__ float4 topLds[TOPN * TOPW];
-    const int nTop = tune.useTop ? min(ANY ? sc.nTop4 : sc.nTop2, TOPN) : 0;
-    for (int i = (int)threadIdx.x; i < nTop * TOPW; i += 256) topLds[i] = nodes[(size_t)(i / TOPW) * RECW + (size_t)(i % TOPW)];
-    __syncthreads();
     const float eps = fr->u.eps, inf = fr->u.inf;
     src.prepare();
     const uint32_t n = src.size();
@@ -397,55 +389,6 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
                 src.store_closest(rayId, triBest >= 0 ? tBest : inf, triBest);
                 active = false;
             }
-        }
-    };
-
-
-    // one visit of a 4-wide any-hit record / a 2-wide closest-hit record (from global memory or from the LDS copy)
-    auto visit4 = [&](const float4 &q0, const float4 &q1, const float4 &q2, const float4 &q3, const float4 &q4, const float4 &q5, const float4 &q6) {
-        if constexpr (ANY) {
-            int r0 = (int)f2u(q6.x), r1 = (int)f2u(q6.y), r2 = (int)f2u(q6.z), r3 = (int)f2u(q6.w);
-            float t0, t1, t2, t3;
-            bool h0 = slab(ro, rdInv, mk3(q0.x, q1.x, q2.x), mk3(q3.x, q4.x, q5.x), t0) && t0 <= tBest;
-            bool h1 = slab(ro, rdInv, mk3(q0.y, q1.y, q2.y), mk3(q3.y, q4.y, q5.y), t1) && t1 <= tBest;
-            // absent children carry NaN boxes: with v_min/v_max NaN semantics their slab test is false, so all
-            // loads are issued up front and the four tests are branch-free (no dependent "is there a child" round trip)
-            bool h2 = slab(ro, rdInv, mk3(q0.z, q1.z, q2.z), mk3(q3.z, q4.z, q5.z), t2) && t2 <= tBest;
-            bool h3 = slab(ro, rdInv, mk3(q0.w, q1.w, q2.w), mk3(q3.w, q4.w, q5.w), t3) && t3 <= tBest;
-            // Any-hit order is free, so leaves are postponed: the first leaf met goes to `leaf`, the lane goes on with an
-            // inner child (or pops one), and leaves are tested in the leaf phase when (nearly) every lane holds one --
-            // both phases run with more lanes busy than when a lane stops at its first leaf.
-            int nxt = RT_NO_CHILD;
-            auto take = [&](bool h, int r) {
-                if (!h) return;
-                if (r < 0 && leaf == 0) { leaf = r; return; }
-                if (nxt == RT_NO_CHILD) { nxt = r; return; }
-                if (r >= 0 && nxt < 0) { const int t = nxt; nxt = r; r = t; }   // go on with the inner node, defer the leaf
-                stk[sp * 64] = (uint32_t)r;
-                sp++;
-            };
-            take(h0, r0); take(h1, r1); take(h2, r2); take(h3, r3);
-            if (nxt == RT_NO_CHILD) pop_or_finish();
-            else ref = nxt;
-        }
-    };
-    auto visit2 = [&](const float4 &a, const float4 &b, const float4 &c, const float4 &d) {
-        if constexpr (!ANY) {
-            float tL, tR;
-            bool hitL = slab(ro, rdInv, f4xyz(a), f4xyz(b), tL) && tL <= tBest;
-            bool hitR = slab(ro, rdInv, f4xyz(c), f4xyz(d), tR) && tR <= tBest;
-            int refL = (int)f2u(a.w), refR = (int)f2u(b.w);
-            if (hitL && hitR) {
-                bool leftFirst = tL < tR;
-                StackEntry e;
-                e.x = (uint32_t)(leftFirst ? refR : refL);
-                e.y = f2u(leftFirst ? tR : tL);
-                stk[sp * 64] = e;
-                sp++;
-                ref = leftFirst ? refL : refR;
-            } else if (hitL || hitR) {
-                ref = hitL ? refL : refR;
-            } else pop_or_finish();
         }
     };
 
@@ -542,21 +485,7 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
             if (__popcll(sm) < tune.minSearch && __ballot(active && (ANY ? leaf != 0 : ref < 0)) != 0ull) break;   // keep the leaf phase dense
             const unsigned long long tI_ = STATS ? clock64() : 0ull;
             if (STATS && lane == 0) { st_[3]++; st_[4] += (unsigned long long)__popcll(sm); }
-            // ---- LDS steps: lanes standing on a top-of-tree record advance without touching global memory
-            if (nTop > 0) {
-                for (;;) {
-                    const bool inTop = active && (uint32_t)ref < (uint32_t)nTop;
-                    if (__ballot(inTop) == 0ull) break;
-                    if (inTop) {
-                        if (STATS) { st_[0]++; }
-                        const float4 *nd = topLds + ref * TOPW;
-                        if constexpr (ANY) visit4(nd[0], nd[1], nd[2], nd[3], nd[4], nd[5], nd[6]);
-                        else visit2(nd[0], nd[1], nd[2], nd[3]);
-                    }
-                }
-            }
-            const bool searchingG = active && (uint32_t)ref < (uint32_t)RT_NO_CHILD;   // the LDS steps may have changed `ref`
-            if (searchingG) {
+            if (searching) {
                 if (STATS) st_[0]++;
                 gathers += ANY ? 7u : 4u;
                 if constexpr (ANY) {
@@ -565,12 +494,48 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
                     // component-wise: [min.x x4][min.y x4][min.z x4][max.x x4][max.y x4][max.z x4][ref x4] = 7 loads, 8th piece unused
                     float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3], q4 = nd[4], q5 = nd[5], q6 = nd[6];
                     pin(q0); pin(q1); pin(q2); pin(q3); pin(q4); pin(q5); pin(q6);
-                    visit4(q0, q1, q2, q3, q4, q5, q6);
+                    int r0 = (int)f2u(q6.x), r1 = (int)f2u(q6.y), r2 = (int)f2u(q6.z), r3 = (int)f2u(q6.w);
+                    float t0, t1, t2, t3;
+                    bool h0 = slab(ro, rdInv, mk3(q0.x, q1.x, q2.x), mk3(q3.x, q4.x, q5.x), t0) && t0 <= tBest;
+                    bool h1 = slab(ro, rdInv, mk3(q0.y, q1.y, q2.y), mk3(q3.y, q4.y, q5.y), t1) && t1 <= tBest;
+                    // absent children carry NaN boxes: with v_min/v_max NaN semantics their slab test is false, so all
+                    // loads are issued up front and the four tests are branch-free (no dependent "is there a child" round trip)
+                    bool h2 = slab(ro, rdInv, mk3(q0.z, q1.z, q2.z), mk3(q3.z, q4.z, q5.z), t2) && t2 <= tBest;
+                    bool h3 = slab(ro, rdInv, mk3(q0.w, q1.w, q2.w), mk3(q3.w, q4.w, q5.w), t3) && t3 <= tBest;
+                    // Any-hit order is free, so leaves are postponed: the first leaf met goes to `leaf`, the lane goes on with an
+                    // inner child (or pops one), and leaves are tested in the leaf phase when (nearly) every lane holds one --
+                    // both phases run with more lanes busy than when a lane stops at its first leaf.
+                    int nxt = RT_NO_CHILD;
+                    auto take = [&](bool h, int r) {
+                        if (!h) return;
+                        if (r < 0 && leaf == 0) { leaf = r; return; }
+                        if (nxt == RT_NO_CHILD) { nxt = r; return; }
+                        if (r >= 0 && nxt < 0) { const int t = nxt; nxt = r; r = t; }   // go on with the inner node, defer the leaf
+                        stk[sp * 64] = (uint32_t)r;
+                        sp++;
+                    };
+                    take(h0, r0); take(h1, r1); take(h2, r2); take(h3, r3);
+                    if (nxt == RT_NO_CHILD) pop_or_finish();
+                    else ref = nxt;
                 } else {
                     const float4 *nd = nodes + (size_t)ref * 4;
                     float4 a = nd[0], b = nd[1], c = nd[2], d = nd[3];
                     pin(a); pin(b); pin(c); pin(d);
-                    visit2(a, b, c, d);
+                    float tL, tR;
+                    bool hitL = slab(ro, rdInv, f4xyz(a), f4xyz(b), tL) && tL <= tBest;
+                    bool hitR = slab(ro, rdInv, f4xyz(c), f4xyz(d), tR) && tR <= tBest;
+                    int refL = (int)f2u(a.w), refR = (int)f2u(b.w);
+                    if (hitL && hitR) {
+                        bool leftFirst = tL < tR;
+                        StackEntry e;
+                        e.x = (uint32_t)(leftFirst ? refR : refL);
+                        e.y = f2u(leftFirst ? tR : tL);
+                        stk[sp * 64] = e;
+                        sp++;
+                        ref = leftFirst ? refL : refR;
+                    } else if (hitL || hitR) {
+                        ref = hitL ? refL : refR;
+                    } else pop_or_finish();
                 }
             }
             if (STATS) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (lane == 0) st_[8] += clock64() - tI_; }
@@ -855,20 +820,18 @@ __global__ void k_accum_tally(const uint32_t *counts, unsigned long long *acc) {
 template <class Src, bool ANY>
 void launch_trace(hipStream_t st, int cus, int depth, const DevFrame *fr, const DevScene &hs, Src src, uint32_t *head, uint32_t *tally,
                   unsigned long long *gatherLoads, TraceTune tune, unsigned long long *stats = nullptr) {
-    // Stack entries: closest-hit defers at most one sibling per inner node on the path to the current node (depth - 1 of them,
-    // 8 B each); any-hit walks 4-wide nodes and can defer three per two levels (4 B each).  Resident 256-thread blocks per CU
-    // follow from the LDS footprint: the stacks plus the LDS copy of the top of the tree (4032 / 2352 bytes).
-    const int need = ANY ? 3 * ((depth + 1) / 2) : std::max(depth - 1, 1);
-    const int s0 = ANY ? 24 : 14, s1 = ANY ? 36 : 24, s2 = ANY ? 48 : 32;
+    // Stack entries: closest-hit defers one sibling per binary level (8 B each); any-hit walks 4-wide nodes and can
+    // defer three per two levels (4 B each).  Resident 256-thread blocks per CU follow from the LDS footprint.
+    const int need = ANY ? 3 * ((depth + 1) / 2) : depth;
+    const int s0 = ANY ? 24 : 16, s1 = ANY ? 36 : 24, s2 = ANY ? 48 : 32;
     const int stack = need <= s0 ? s0 : (need <= s1 ? s1 : s2);
-    const int topBytes = ANY ? 21 * 7 * 16 : 63 * 4 * 16;
-    const int perCU = std::max(1, std::min(8, (160 * 1024) / (256 * stack * (ANY ? 4 : 8) + topBytes)));
+    const int perCU = std::max(1, std::min(8, (160 * 1024) / (256 * stack * (ANY ? 4 : 8))));
     const float4 *nodes = ANY ? hs.w4 : hs.wnodesW;
     dim3 g((unsigned)(cus * perCU)), b(256);
 #define RT_LAUNCH_TRACE(ST, LB) do { if (stats) hipLaunchKernelGGL((k_trace<Src, ANY, ST, LB, true>), g, b, 0, st, fr, nodes, hs.pairs, src, head, tally, gatherLoads, tune, stats); \
         else hipLaunchKernelGGL((k_trace<Src, ANY, ST, LB, false>), g, b, 0, st, fr, nodes, hs.pairs, src, head, tally, gatherLoads, tune, (unsigned long long *)nullptr); } while (0)
 #define RT_LAUNCH_TRACE_LB(ST) do { if (tune.leafb >= 4) RT_LAUNCH_TRACE(ST, 4); else RT_LAUNCH_TRACE(ST, 2); } while (0)
-    if (stack == s0) RT_LAUNCH_TRACE_LB((ANY ? 24 : 14));
+    if (stack == s0) RT_LAUNCH_TRACE_LB((ANY ? 24 : 16));
     else if (stack == s1) RT_LAUNCH_TRACE_LB((ANY ? 36 : 24));
     else RT_LAUNCH_TRACE_LB((ANY ? 48 : 32));
 #undef RT_LAUNCH_TRACE_LB
@@ -884,7 +847,7 @@ struct RtWave {
     std::string err;
     int cus = 256;
     size_t budgetBytes = (size_t)8 << 30;   // ray-queue budget per context; 288 GB of HBM make this cheap
-    TraceTune tune{32, 16, 0, 2, 0, 1};   // chunk 0 = run length chosen in the kernel from the queue size
+    TraceTune tune{32, 16, 0, 2, 0};   // chunk 0 = run length chosen in the kernel from the queue size
     // allocations
     size_t slotsCap = 0;      // per-frame arrays sized for this many pixel slots
     size_t chunkBytes = 0;    // bytes of the per-chunk arena
@@ -903,7 +866,6 @@ RtWave *rt_wave_create(int cus) {
     if (const char *e = getenv("RT_CHUNK")) { int v = atoi(e); w->tune.chunk = v <= 0 ? 0 : std::max(8, std::min(1 << 20, v)); }   // 0 = from the queue size
     if (const char *e = getenv("RT_DEBUG_SKIP_TRAVERSAL")) w->tune.skipTraversal = atoi(e);
     if (const char *e = getenv("RT_LEAFB")) w->tune.leafb = atoi(e);
-    if (const char *e = getenv("RT_LDS_TOP")) w->tune.useTop = atoi(e);
     if (const char *e = getenv("RT_MIN_SEARCH")) w->tune.minSearch = std::max(0, std::min(64, atoi(e)));
     return w;
 }
