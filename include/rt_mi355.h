@@ -305,6 +305,8 @@ void rt_make_uniforms(const RtRenderParams *p, const RtCamera *cam, const float 
 /* gather_model_triangles (include/scene/bvh.h:135, src/scene/bvh.cpp:225-246): 9 floats (v0,e1,e2) per
  * index triple after the model matrix.  Returns the triangle count. */
 int rt_gather_triangles(const float *positions, const uint32_t *indices, int nIdx, const float *M16, float *outTris9);
+/* the same with the vertex count: RT_ERR_INVALID if any index is out of range (use this one for data read from files) */
+int rt_gather_triangles_checked(const float *positions, int nVerts, const uint32_t *indices, int nIdx, const float *M16, float *outTris9);
 
 /* build_bvh (include/scene/bvh.h:102, src/scene/bvh.cpp:94-137) + the packing half of upload_bvh_tbo
  * (:147-204).  nodes12 needs room for 2*nTris*12 floats, tris12 for nTris*12.  Returns the node count. */

@@ -205,6 +205,7 @@ SIGNATURES = {
     "rt_camera_moved": (C.c_int, [_FP, _FP]),
     "rt_make_uniforms": (None, [C.POINTER(RtRenderParams), C.POINTER(RtCamera), _FP, _FP, _FP] + [C.c_int] * 9 + [C.POINTER(RtUniforms)]),
     "rt_gather_triangles": (C.c_int, [_FP, _U32P, C.c_int, _FP, _FP]),
+    "rt_gather_triangles_checked": (C.c_int, [_FP, C.c_int, _U32P, C.c_int, _FP, _FP]),
     "rt_build_bvh": (C.c_int, [_FP, C.c_int, _FP, _FP]),
     "rt_load_obj": (C.c_int, [C.c_char_p, C.POINTER(_FP), C.POINTER(C.c_int), C.POINTER(_U32P), C.POINTER(C.c_int)]),
     "rt_load_png": (C.c_int, [C.c_char_p, C.POINTER(_U8P), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
@@ -355,9 +356,9 @@ def gather_triangles(positions, indices, model=None) -> np.ndarray:
     idx = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1)
     m = default_bvh_transform() if model is None else _f32(model)
     out = np.zeros((idx.size // 3, 9), np.float32)
-    n = lib().rt_gather_triangles(_fp(pos), idx.ctypes.data_as(_U32P), idx.size, _fp(m), _fp(out))
+    n = lib().rt_gather_triangles_checked(_fp(pos), pos.size // 3, idx.ctypes.data_as(_U32P), idx.size, _fp(m), _fp(out))
     if n < 0:
-        raise RtError(n, "rt_gather_triangles")
+        raise RtError(n, "rt_gather_triangles: index out of range" if n == RT_ERR_INVALID else "rt_gather_triangles")
     return out[:n]
 
 

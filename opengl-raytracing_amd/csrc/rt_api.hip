@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -85,6 +86,12 @@ static int fail(RtContext *c, int code, const char *fmt, ...) {
     va_end(ap);
     if (c) c->err = buf; else g_createError = buf;
     return code;
+}
+// No C++ exception crosses the C ABI: std::bad_alloc etc. from the host-side repacking become status codes.
+template <class F> static int guarded(RtContext *c, const char *what, F &&body) {
+    try { return body(); }
+    catch (const std::bad_alloc &) { return fail(c, RT_ERR_IO, "%s: out of host memory", what); }
+    catch (...) { return fail(c, RT_ERR_INVALID, "%s: unexpected exception", what); }
 }
 static hipError_t sync_all(RtContext *c) {
     hipError_t e = hipSuccess;
@@ -349,7 +356,7 @@ void rt_destroy(RtContext *c) {
     (void)rt_comm_destroy(c);
     free_targets(c);
     for (int i = 0; i < RT_MAX_LANES; ++i) { if (c->wave[i]) rt_wave_destroy(c->wave[i]); if (c->dFrame[i]) (void)hipFree(c->dFrame[i]); if (c->evDone[i]) (void)hipEventDestroy(c->evDone[i]); }
-    for (int i = 1; i < RT_MAX_LANES; ++i) if (c->lanes[i]) (void)hipStreamDestroy(c->lanes[i]);
+    for (int i = 0; i < RT_MAX_LANES; ++i) if (c->lanes[i]) (void)hipStreamDestroy(c->lanes[i]);   // c->stream is lanes[0]
     if (c->dWNodes) (void)hipFree(c->dWNodes);
     if (c->dW4) (void)hipFree(c->dW4);
     if (c->dWNodesW) (void)hipFree(c->dWNodesW);
@@ -360,13 +367,13 @@ void rt_destroy(RtContext *c) {
     if (c->dStaging) (void)hipFree(c->dStaging);
     for (auto &ev : c->pending) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     for (auto &p : c->freeEvents) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
-    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
 int rt_upload_bvh(RtContext *c, const float *nodes12, int nNodes, const float *tris12, int nTris) {
     if (!c) return RT_ERR_INVALID;
     if (nNodes < 0 || nTris < 0 || (nNodes > 0 && !nodes12) || (nTris > 0 && !tris12)) return fail(c, RT_ERR_INVALID, "rt_upload_bvh: bad arguments");
+    return guarded(c, "rt_upload_bvh", [&]() -> int {
     (void)hipSetDevice(c->cfg.device);
     HIP_TRY(c, sync_all(c));
     if (c->dWNodes) (void)hipFree(c->dWNodes);
@@ -528,6 +535,7 @@ int rt_upload_bvh(RtContext *c, const float *nodes12, int nNodes, const float *t
     std::memcpy(c->rootMin, nodes12, 12);
     std::memcpy(c->rootMax, nodes12 + 4, 12);
     return RT_OK;
+    });
 }
 
 int rt_build_bvh_gpu(RtContext *c, const float *tris9, int nTris, float *nodes12, float *tris12) {
@@ -545,6 +553,7 @@ int rt_upload_env(RtContext *c, const uint8_t *faces, int faceSize, int channels
                                          128, 128, 255, 255, 128, 128, 255, 255, 128, 128, 255, 255};   // cubemap.cpp:13
     if (!faces) { faces = dummy; faceSize = 1; channels = 4; }
     if (faceSize <= 0 || (channels != 3 && channels != 4)) return fail(c, RT_ERR_INVALID, "rt_upload_env: faceSize=%d channels=%d", faceSize, channels);
+    return guarded(c, "rt_upload_env", [&]() -> int {
     const size_t texels = (size_t)6 * faceSize * faceSize;
     std::vector<uint8_t> rgba(texels * 4);
     for (size_t i = 0; i < texels; ++i) {
@@ -560,6 +569,7 @@ int rt_upload_env(RtContext *c, const uint8_t *faces, int faceSize, int channels
     HIP_TRY(c, hipMemcpy(c->dEnv, rgba.data(), texels * 4, hipMemcpyHostToDevice));
     c->envSize = faceSize;
     return RT_OK;
+    });
 }
 
 int rt_resize(RtContext *c, int w, int h) {

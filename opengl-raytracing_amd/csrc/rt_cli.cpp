@@ -259,7 +259,8 @@ int main(int argc, char **argv) {
             if ((rc = rt_load_obj(obj.c_str(), &pos, &nv, &idx, &ni)) != RT_OK) die(ctx, "rt_load_obj", rc);
             const size_t at = tris9.size();
             tris9.resize(at + (size_t)(ni / 3) * 9);
-            const int nt = rt_gather_triangles(pos, idx, ni, M, tris9.data() + at);
+            const int nt = rt_gather_triangles_checked(pos, nv, idx, ni, M, tris9.data() + at);
+            if (nt < 0) die(ctx, "rt_gather_triangles_checked", nt);
             tris9.resize(at + (size_t)nt * 9);
             RT_SAY("[OBJ] %s: %d vertices, %d triangles\n", obj.c_str(), nv, nt);
             rt_free(pos); rt_free(idx);

@@ -168,6 +168,9 @@ static int decode_png(const std::vector<uint8_t> &file, std::vector<uint8_t> &pi
         default: return RT_ERR_UNSUPPORTED;
     }
     const size_t stride = (size_t)W * srcCh;
+    // a corrupt or hostile IHDR must not make us allocate gigabytes: deflate expands at most ~1032:1, so the declared image
+    // cannot be larger than that multiple of the compressed data actually present
+    if ((size_t)W > ((size_t)1 << 24) || (size_t)H > ((size_t)1 << 24) || (stride + 1) * (size_t)H > idat.size() * 1032 + 65536) return RT_ERR_IO;
     std::vector<uint8_t> raw((stride + 1) * (size_t)H);
     uLongf rawLen = (uLongf)raw.size();
     if (uncompress(raw.data(), &rawLen, idat.data(), (uLong)idat.size()) != Z_OK || rawLen != raw.size()) return RT_ERR_IO;
@@ -207,6 +210,14 @@ static int decode_png(const std::vector<uint8_t> &file, std::vector<uint8_t> &pi
         pix.swap(img);
     }
     return RT_OK;
+}
+
+// No C++ exception may cross the C ABI (include/rt_mi355.h): allocation failures and anything else thrown by the standard
+// library inside an entry point become a status code.
+template <class F> static int guarded(F &&body) {
+    try { return body(); }
+    catch (const std::bad_alloc &) { return RT_ERR_IO; }
+    catch (...) { return RT_ERR_INVALID; }
 }
 
 }  // namespace rthost
@@ -375,9 +386,17 @@ int rt_gather_triangles(const float *positions, const uint32_t *indices, int nId
     return n;
 }
 
+int rt_gather_triangles_checked(const float *positions, int nVerts, const uint32_t *indices, int nIdx, const float *M, float *out) {
+    if (!positions || !indices || !M || !out || nIdx < 0 || nVerts < 0) return RT_ERR_INVALID;
+    for (int k = 0; k < nIdx; ++k)
+        if (indices[k] >= (uint32_t)nVerts) return RT_ERR_INVALID;
+    return rt_gather_triangles(positions, indices, nIdx, M, out);
+}
+
 int rt_build_bvh(const float *tris9, int nTris, float *nodes12, float *tris12) {
     if (nTris < 0 || (nTris > 0 && (!tris9 || !nodes12 || !tris12))) return RT_ERR_INVALID;
     if (nTris == 0) return 0;
+    return guarded([&]() -> int {
     std::vector<TriRef> refs((size_t)nTris);
     for (int i = 0; i < nTris; ++i) {
         F3 mn, mx;
@@ -419,17 +438,20 @@ int rt_build_bvh(const float *tris9, int nTris, float *nodes12, float *tris12) {
         o[8] = t[6]; o[9] = t[7]; o[10] = t[8]; o[11] = 0.0f;
     }
     return (int)nodes.size();
+    });
 }
 
 int rt_load_obj(const char *path, float **positions, int *nVerts, uint32_t **indices, int *nIdx) {
     if (!path || !positions || !nVerts || !indices || !nIdx) return RT_ERR_INVALID;
     FILE *f = std::fopen(path, "rb");
     if (!f) return RT_ERR_IO;
+    char *line = nullptr;          // getline: a face record may be arbitrarily long (fgets with a fixed buffer would cut it into wrong faces)
+    size_t cap = 0;
+    const int rc = guarded([&]() -> int {
     std::vector<float> pos;
     std::vector<uint32_t> idx;
     std::vector<long> face;
-    char line[4096];
-    while (std::fgets(line, sizeof line, f)) {
+    while (getline(&line, &cap, f) >= 0) {
         const char *s = line;
         while (*s == ' ' || *s == '\t') ++s;
         if (s[0] == 'v' && (s[1] == ' ' || s[1] == '\t')) {
@@ -446,7 +468,7 @@ int rt_load_obj(const char *path, float **positions, int *nVerts, uint32_t **ind
                 if (end == q) break;
                 const long nv = (long)(pos.size() / 3);
                 if (v < 0) v = nv + v + 1;           // relative index
-                if (v < 1 || v > nv) { std::fclose(f); return RT_ERR_IO; }
+                if (v < 1 || v > nv) return RT_ERR_IO;
                 face.push_back(v - 1);
                 q = end;
                 while (*q && *q != ' ' && *q != '\t' && *q != '\n' && *q != '\r') ++q;
@@ -456,37 +478,44 @@ int rt_load_obj(const char *path, float **positions, int *nVerts, uint32_t **ind
             }
         }
     }
-    std::fclose(f);
     *nVerts = (int)(pos.size() / 3);
     *nIdx = (int)idx.size();
     *positions = (float *)std::malloc(std::max<size_t>(pos.size(), 1) * sizeof(float));
     *indices = (uint32_t *)std::malloc(std::max<size_t>(idx.size(), 1) * sizeof(uint32_t));
-    if (!*positions || !*indices) return RT_ERR_IO;
+    if (!*positions || !*indices) { std::free(*positions); std::free(*indices); *positions = nullptr; *indices = nullptr; return RT_ERR_IO; }
     std::memcpy(*positions, pos.data(), pos.size() * sizeof(float));
     std::memcpy(*indices, idx.data(), idx.size() * sizeof(uint32_t));
     return RT_OK;
+    });
+    std::free(line);
+    std::fclose(f);
+    return rc;
 }
 
 int rt_load_png(const char *path, uint8_t **pixels, int *width, int *height, int *channels) {
     if (!path || !pixels || !width || !height || !channels) return RT_ERR_INVALID;
     FILE *f = std::fopen(path, "rb");
     if (!f) return RT_ERR_IO;
-    std::vector<uint8_t> file;
-    uint8_t buf[65536];
-    size_t got;
-    while ((got = std::fread(buf, 1, sizeof buf, f)) > 0) file.insert(file.end(), buf, buf + got);
+    const int rc = guarded([&]() -> int {
+        std::vector<uint8_t> file;
+        uint8_t buf[65536];
+        size_t got;
+        while ((got = std::fread(buf, 1, sizeof buf, f)) > 0) file.insert(file.end(), buf, buf + got);
+        std::vector<uint8_t> pix;
+        const int rcd = decode_png(file, pix, *width, *height, *channels);
+        if (rcd != RT_OK) return rcd;
+        *pixels = (uint8_t *)std::malloc(pix.size());
+        if (!*pixels) return RT_ERR_IO;
+        std::memcpy(*pixels, pix.data(), pix.size());
+        return RT_OK;
+    });
     std::fclose(f);
-    std::vector<uint8_t> pix;
-    const int rc = decode_png(file, pix, *width, *height, *channels);
-    if (rc != RT_OK) return rc;
-    *pixels = (uint8_t *)std::malloc(pix.size());
-    if (!*pixels) return RT_ERR_IO;
-    std::memcpy(*pixels, pix.data(), pix.size());
-    return RT_OK;
+    return rc;
 }
 
 int rt_save_png(const char *path, const uint8_t *pixels, int width, int height, int channels, int flipY) {
     if (!path || !pixels || width <= 0 || height <= 0 || channels < 1 || channels > 4) return RT_ERR_INVALID;
+    return guarded([&]() -> int {
     static const uint8_t ctype[5] = {0, 0, 4, 2, 6};
     const size_t stride = (size_t)width * channels;
     std::vector<uint8_t> raw((stride + 1) * (size_t)height);
@@ -523,6 +552,7 @@ int rt_save_png(const char *path, const uint8_t *pixels, int width, int height, 
     chunk("IEND", nullptr, 0);
     const bool ok = std::fclose(f) == 0;
     return ok ? RT_OK : RT_ERR_IO;
+    });
 }
 
 int rt_cubemap_from_cross(const uint8_t *img, int width, int height, int channels, uint8_t *faces) {

@@ -179,3 +179,30 @@ def test_tile_layout_mirror():
         assert np.array_equal(tiles.assemble(blocks, w, h), img)
         masks = [tiles.owner_mask(w, h, r, world) for r in range(world)]
         assert np.array_equal(sum(m.astype(int) for m in masks), np.ones((h, w), int))
+
+
+def test_host_entry_points_reject_bad_input(tmp_path):
+    """nothing thrown across the C ABI, sizes from files are not trusted, indices are range-checked."""
+    import struct
+    import zlib
+    # a PNG whose IHDR claims 1 000 000 x 1 000 000 pixels over a few bytes of IDAT: refused, not std::bad_alloc
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d))
+    bomb = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 1000000, 1000000, 8, 2, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(b"\0" * 64)) + chunk(b"IEND", b"")
+    (tmp_path / "bomb.png").write_bytes(bomb)
+    with pytest.raises(rt.RtError) as e:
+        rt.load_png(tmp_path / "bomb.png")
+    assert e.value.code == rt.RT_ERR_IO
+    # out-of-range vertex index
+    with pytest.raises(rt.RtError):
+        rt.gather_triangles(np.zeros((3, 3), np.float32), np.array([0, 1, 7], np.uint32))
+    # a face record far longer than any fixed line buffer: 3000 vertices in one polygon -> 2998 fan triangles
+    n = 3000
+    ang = np.linspace(0, 2 * np.pi, n, endpoint=False)
+    with open(tmp_path / "ngon.obj", "w") as f:
+        for a in ang:
+            f.write(f"v {np.cos(a):.6f} {np.sin(a):.6f} 0\n")
+        f.write("f " + " ".join(f"{i + 1}/{i + 1}/{i + 1}" for i in range(n)) + "\n")
+    v, idx = rt.load_obj(tmp_path / "ngon.obj")
+    assert v.shape == (n, 3) and idx.size == (n - 2) * 3 and idx.max() == n - 1
+    assert np.array_equal(idx.reshape(-1, 3)[:, 0], np.zeros(n - 2, np.uint32))

@@ -1,4 +1,4 @@
-import sys,time; sys.path.insert(0,"."); sys.path.insert(0,"tests")
+import sys,time,os; R=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0,R); sys.path.insert(0,R+"/tests")
 import opengl_raytracing_amd as rt, scenes
 W,H=1920,1080; world=int(sys.argv[1]) if len(sys.argv)>1 else 1
 nodes,tris=scenes.bunny_bvh(6); faces=scenes.env_faces("Sky_01"); p=rt.default_render_params(); p.sppPerFrame=4; cam=scenes.camera(sys.argv[2] if len(sys.argv)>2 else "closeup")
