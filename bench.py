@@ -31,7 +31,11 @@ for p in (str(ROOT), str(ROOT / "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-L1_GATHER_PEAK_G = 256 * 2.4   # G lane-loads/s: one divergent 16-byte lane-load per clock and CU (tools/gather.hip)
+# Ceiling of the vector L1's gather path in G lane-loads/s (16 B per lane and load), per access shape, from tools/gather.hip with the
+# table L2-resident and 20 waves/CU (profiles/r02_gather_microbench_pmc.txt: the PMC passes show TCP_TOTAL_CACHE_ACCESSES = one per
+# divergent lane-load, processed at 0.8-1.0 per clock and CU): 64 lanes x 8 x dwordx4 from one 128-byte record per lane (the any-hit
+# kernel's 4-wide node) 1.05e9 loads in 1.502 ms; 64 lanes x 4 x dwordx4 from a 64-byte record (2-wide node) 5.24e8 in 0.888 ms.
+L1_GATHER_PEAK_G = {"trace_shadow": 1.05e9 / 1.502e-3 / 1e9, "trace_gi": 5.24e8 / 0.888e-3 / 1e9, "trace_primary": 5.24e8 / 0.888e-3 / 1e9}
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 W, H, SPP = 1920, 1080, 4
 
@@ -74,6 +78,8 @@ def main():
     ap.add_argument("--no-default-camera", action="store_true")
     ap.add_argument("--gather-every", type=int, default=1, help="N > 1 GPUs: gather COLOR0 to rank 0 every k-th frame (1 = every frame; a static "
                     "camera's history is tile-local, so BASELINE configs[4] needs one gather per 32 accumulated frames)")
+    ap.add_argument("--force-gather", action="store_true", help="rehearsal on one GPU: run the N > 1 code path (process group, communicator, "
+                    "gather per frame) with a world of one; launch with torch.distributed.run --nproc-per-node 1")
     ap.add_argument("--gather", default="native", choices=["native", "torch"], help="N > 1: the library's own RCCL communicator (C ABI) or torch.distributed")
     # other BASELINE.json configurations, for side measurements (the default line is configs[1], the one `metric` is quoted on)
     ap.add_argument("--size", default="1920x1080", help="framebuffer WxH (configs[3]: 3840x2160)")
@@ -98,7 +104,8 @@ def main():
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
         args.gpus = world
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    multi = world > 1 or args.force_gather      # the tile-parallel code path (process group, communicator, gathers)
+    if multi:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
@@ -142,7 +149,7 @@ def main():
 
         ren = make_renderer(False)
         gatherer = None
-        if world > 1:
+        if multi:
             # the exchange runs inside the library (rt_comm_init / rt_gather_frame: RCCL behind the C ABI).  If its communicator
             # cannot be brought up on this node the run falls back to the same exchange issued through torch.distributed -- on
             # every rank alike -- and says so in the JSON line.
@@ -179,7 +186,7 @@ def main():
         torch.cuda.synchronize()
         if timed_stage:
             ren.enable_stage_timing(True)
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -187,7 +194,7 @@ def main():
             step(f)
         ren.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         dt = time.perf_counter() - t0
         stages = ren.stage_times() if timed_stage else None
@@ -196,12 +203,12 @@ def main():
         ren.close()
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         cc = torch.tensor(list(cnt.to_dict().values()), dtype=torch.int64, device="cuda")
-        if world > 1:
+        if multi:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dist.all_reduce(cc, op=dist.ReduceOp.SUM)
         total = rt.RtCounters(*[int(v) for v in cc.tolist()])
         tr = torch.tensor([traced.rays, traced.frames], dtype=torch.int64, device="cuda")
-        if world > 1:
+        if multi:
             dist.all_reduce(tr, op=dist.ReduceOp.SUM)
         frames_all = max(int(tr[1].item()) // world, 1)
         traced_per_frame = int(tr[0].item()) * steps // frames_all // steps if traced.frames else 0
@@ -309,10 +316,12 @@ def main():
         if name in gl and tr.frames:
             per_launch = gl[name] / frames_tr / per_frame_launches
             rate = per_launch / (avg_ms * 1e-3) / 1e9
-            l1 = {"unit": "G lane-loads/s (16 B each)", "lane_loads_per_launch": per_launch, "achieved": rate, "peak": L1_GATHER_PEAK_G,
-                  "frac": rate / L1_GATHER_PEAK_G, "bytes_per_s_TB": rate * 16 / 1e3,
-                  "peak_source": "256 CUs x 2.4 GHz x 1 divergent lane-load/clk (tools/gather.hip; per-shape ceilings and the PMC "
-                                 "cross-check in profiles/README.md)"}
+            pk = L1_GATHER_PEAK_G[name]
+            l1 = {"unit": "G lane-loads/s (16 B each)", "lane_loads_per_launch": per_launch, "achieved": rate, "peak": pk,
+                  "frac": rate / pk, "bytes_per_s_TB": rate * 16 / 1e3,
+                  "peak_source": "tools/gather.hip, fully divergent lanes, this kernel's node record shape (profiles/r02_gather_microbench_pmc.txt: "
+                                 "~1 TCP cache access per clock and CU).  Lanes of a wave that read the same 16 bytes are merged by the L1, so the "
+                                 "kernel's own count over-states its TCP accesses by ~1.4x: profiles/README.md gives the PMC figure"}
         roofline = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                     "avg_launch_ms": avg_ms, "launches": launches, "algorithmic_bytes_per_launch": bytes_per_launch,
@@ -336,7 +345,7 @@ def main():
                                + ("procedural bunny stand-in (icosphere subdiv %d" % args.subdiv if args.scene == "bunny" else "1M-triangle multi-object scene (")
                                + ", %d tris, median-split BVH), %dx%d, %d spp, GI 1 bounce + AO 4, Sky_01 env, close-up camera (-2,1.5,1.0)" % (tris.shape[0], W, H, SPP),
                    "pipeline": args.pipeline, "tiles": "16x16 round-robin over ranks" if world > 1 else "single GPU",
-                   "gather": gather_path if world > 1 else None,
+                   "gather": gather_path if multi else None,
                    "rays_per_frame": rays // args.steps, "msample_per_s": npix * SPP * args.steps / res["seconds"] / 1e6,
                    "hit_pixels": res["counters"].hitPixels // args.steps,
                    "rays_traversed_per_frame": res["traced_per_frame"],
@@ -392,7 +401,7 @@ def main():
                                "frame_seconds_estimate": {"threads_1": rays / args.steps / (r1 / t1), "threads_all": rays / args.steps / (rn / tn)},
                                "note": "the CPU traces every reference ray; the GPU pipeline skips duplicates (config.ray_accounting), so compare "
                                        "frame times (frame_seconds_estimate vs ms_per_step), or value_traversed, not the two Mray/s figures"}
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

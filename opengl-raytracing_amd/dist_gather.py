@@ -145,7 +145,21 @@ class NativeGatherer:
         self.gather_every = max(1, int(gather_every))
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        ids = [comm_unique_id() if self.rank == 0 else None]
+        # every rank first proves that it can load RCCL and make an id (only rank 0's is used); the outcome is agreed on BEFORE
+        # the collective ncclCommInitRank, so that one rank without a usable librccl cannot leave the others waiting in it
+        err = None
+        try:
+            my_id = comm_unique_id()
+        except Exception as e:   # noqa: BLE001
+            my_id, err = None, e
+        if self.world > 1 or dist.is_initialized():
+            ok = torch.tensor([0.0 if err else 1.0], device=torch.device("cuda", torch.cuda.current_device()))
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+            if ok.item() == 0:
+                raise RuntimeError(f"RCCL is not usable on every rank (this rank: {err!r})")
+        elif err:
+            raise err
+        ids = [my_id if self.rank == 0 else None]
         if self.world > 1:
             dist.broadcast_object_list(ids, src=0, group=group)      # 128 bytes over the control plane
         renderer.comm_init(ids[0])
