@@ -11,8 +11,9 @@
 //   * sin/cos/exp2/log2/pow are the polynomial routines below (<= 2 ulp vs libm on the ranges
 //     the shaders use; checked by tests/test_oracle_math.py), pow(x,y) = exp2(y*log2(x)) as
 //     GPUs evaluate GLSL pow.
-// parity unpinned: the reference ships no golden vectors; the KATs in
-// SURVEY.md 8c are checked by tests/test_oracle_kat.py.
+// Pins: the reference ships no golden vectors; the KATs in SURVEY.md 8c are checked by
+// tests/test_oracle_kat.py, and the frames / rays the reference's own GLSL produced on SwiftShader by tests/test_glsl_reference.py
+// (to a tolerance: that driver's transcendentals are its own).  The precision a desktop GL driver gives these functions is unpinnable.
 #pragma once
 #include <cmath>
 #include <cstdint>

@@ -11,9 +11,11 @@
 // Float model: oracle/orc_math.h.  Parity status: the reference has no tests or goldens; this
 // file is pinned against the reference's own GLSL executed in the build container by SwiftShader (oracle/glsl_ref.py,
 // fixtures tests/golden/glsl_*.npz, checked by tests/test_glsl_reference.py): analytic-scene frames, TAA, motion,
-// materials, cube map, present pass and the BVH primitives (nodeFetch/triFetch/aabbHit/triHit).  The traversal LOOPS
-// of traceBVH/traceBVHShadow cannot be executed by that SwiftShader build and stay "parity unpinned" by execution;
-// they are pinned only by the KATs of SURVEY.md 8c (tests/test_oracle_kat.py).
+// materials, cube map, present pass, the BVH primitives (nodeFetch/triFetch/aabbHit/triHit) and -- since round 2 -- the
+// traversal LOOPS of traceBVH/traceBVHShadow, ray by ray (2 816 rays, 552 of them equal-t ties that expose the visit
+// order) and as whole BVH frames through rt.frag.  One load-time rewrite makes that possible (SwiftShader 4.1 mis-executes
+// `continue` in that loop; `if (C) continue;` -> `if (!(C)) {...}`, oracle/glsl_ref.py structured_continue).  Not pinnable:
+// what GLSL leaves to the driver (transcendentals, contraction, min/max of NaN), see DESIGN.md section 2.
 #include <algorithm>
 #include <atomic>
 #include <cstdio>

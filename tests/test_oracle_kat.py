@@ -2,8 +2,8 @@
 structural KATs, GL-semantics checks, and the committed golden fixtures (tests/golden/).
 
 The reference has no tests, goldens or fixtures for this path; besides the GLSL-executed fixtures of
-tests/test_glsl_reference.py (which cannot cover the BVH traversal loops: "parity unpinned" there), these are
-the strongest pins available: uint32 RNG KATs are exact; float KATs follow closed forms."""
+tests/test_glsl_reference.py (analytic and BVH frames, traversal loops ray by ray) these pin the integer side exactly:
+uint32 RNG KATs are exact; float KATs follow closed forms."""
 import ctypes as C
 import math
 from pathlib import Path
