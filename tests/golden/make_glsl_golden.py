@@ -6,7 +6,7 @@ SwiftShader libraries inside the `kaleido` wheel); the fixtures it writes are pl
 targets the reference shader produced, as float16 bit patterns.
 
     python tests/golden/make_glsl_golden.py           # rewrites tests/golden/glsl_*.npz and prints agreement with the oracle
-    python tests/golden/make_glsl_golden.py H I       # only the named sections (A-G: round 1, H-I: the BVH traversal loops)
+    python tests/golden/make_glsl_golden.py H I J     # only the named sections (A-G: round 1, H-I: the BVH traversal loops, J: TAA weight regimes)
 
 Frame f of a fixture was rendered with `prev` = the shader's own COLOR0 of frame f-1 (stored as color{f-1}),
 so checkers feed every implementation the same history and compare frame by frame without drift.
@@ -200,6 +200,33 @@ def bvh_frames(g, faces):
         nodes, tris, None)
 
 
+def taa_regimes(g, faces):
+    """J. 34 consecutive frames of one static view (BVH scene, 1 spp): resolveTAA's still branch switches its history weight from
+    uTaaHistoryMinWeight (0.85) to Avg (0.92) at uFrameIndex 8 and to Max (0.96) at 32 (rt_taa.glsl:91-104).  The whole chain runs
+    on the reference GLSL; the fixture keeps the frames around the switches with the history each of them read."""
+    v, fidx = rt.meshgen.bunny_standin(2)
+    nodes, tris = orc.build_bvh(orc.gather_triangles(v, fidx))
+    W, H = 48, 36
+    p = orc.default_render_params()
+    cam = orc.default_camera(); cam.pos[0], cam.pos[1], cam.pos[2], cam.yaw, cam.pitch, cam.aspect = -2.0, 1.5, 1.0, -90.0, 0.0, W / H
+    keep = (0, 1, 7, 8, 9, 31, 32, 33)
+    d = {"frames": np.array(keep, np.int32), "nodes12": nodes, "tris12": tris, "env": faces}
+    prev = None
+    for f in range(34):
+        u = orc.frame_uniforms(p, cam, W, H, f, True, nodes.shape[0], tris.shape[0])
+        got = g.render(u, nodes, tris, faces, prev)
+        if f in keep:
+            want, _ = orc.render(u, nodes, tris, faces, prev)
+            report("glsl_bvh_taa_regimes_48x36", f, got, want)
+            d[f"uniforms{f}"] = ubytes(u)
+            if prev is not None:
+                d[f"prev{f}"] = prev
+            for k, a in zip(("color", "motion", "gpos", "gnrm"), got):
+                d[f"{k}{f}"] = a
+        prev = got[0]
+    np.savez_compressed(HERE / "glsl_bvh_taa_regimes_48x36.npz", **d)
+
+
 def main():
     g = GlslReference()
     print("GL:", g.version)
@@ -210,7 +237,9 @@ def main():
             trace_kat(g)
         if "I" in only:
             bvh_frames(g, faces)
-        if only <= {"H", "I"}:
+        if "J" in only:
+            taa_regimes(g, faces)
+        if only <= {"H", "I", "J"}:
             return
 
     # A. analytic scene, gradient sky, defaults (BASELINE config 1 in miniature), 3 frames of TAA
@@ -322,6 +351,7 @@ def main():
 
     trace_kat(g)
     bvh_frames(g, faces)
+    taa_regimes(g, faces)
 
 
 if __name__ == "__main__":

@@ -102,6 +102,28 @@ def test_oracle_matches_reference_glsl_bvh_primitives(orc):
     assert np.median(rel) < 1e-6 and np.percentile(rel, 95) < 5e-6
 
 
+def check_taa_regimes(d, render):
+    """render(u, prev) -> four targets.  Frames around the history-weight switches of resolveTAA (rt_taa.glsl:91-104: 0.85 below
+    frame 8, 0.92 below 32, 0.96 from 32 on), each with the history the reference GLSL itself read."""
+    for f in [int(x) for x in d["frames"]]:
+        u = rt.RtUniforms.from_buffer_copy(d[f"uniforms{f}"].tobytes())
+        assert u.frameIndex == f and u.cameraMoved == 0 and u.enableTAA == 1
+        prev = d[f"prev{f}"] if f > 0 else None
+        got = render(u, prev)
+        for k, a in zip(("color", "motion", "gpos", "gnrm"), got):
+            b = d[f"{k}{f}"]
+            diff = np.where(np.isfinite(h2f(a)) & np.isfinite(h2f(b)), h2f(a) - h2f(b), 0.0)
+            assert float(np.sqrt(np.mean(diff * diff))) < RMSE_TOL and float(np.mean(a == b)) >= EXACT_MIN, (f, k)
+
+
+def test_oracle_matches_reference_glsl_taa_weight_regimes(orc):
+    d = np.load(GOLDEN / "glsl_bvh_taa_regimes_48x36.npz")
+    check_taa_regimes(d, lambda u, prev: orc.render(u, d["nodes12"], d["tris12"], d["env"], prev)[0])
+    # the three weights really are in play: frame f blends (1 - w) of its own radiance into the history
+    c7, c8 = h2f(d["color7"]), h2f(d["color8"])
+    assert np.abs(c8 - c7).mean() > 0
+
+
 def check_trace_kat(tag, d, closest, any_hit):
     """closest(i) -> (hit, t, p[3], n[3]); any_hit(i) -> bool, for ray i of fixture section `tag`.  Shared with the GPU test.
     Rays lying IN a box plane of an axis they do not move along make a slab product 0 * inf = NaN; GLSL leaves min/max of a NaN

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import opengl_raytracing_amd as rt
-from test_glsl_reference import FRAME_FIXTURES, check_targets, check_trace_kat
+from test_glsl_reference import FRAME_FIXTURES, check_targets, check_taa_regimes, check_trace_kat
 
 pytestmark = pytest.mark.gpu
 GOLDEN = Path(__file__).resolve().parent / "golden"
@@ -52,6 +52,30 @@ def test_hip_megakernel_matches_reference_glsl_bvh_frames(name):
                 r.write_target(rt.RT_TARGET_COLOR, d[f"color{f - 1}"])
             r.render_frame(rt.RtUniforms.from_buffer_copy(d["uniforms"][f].tobytes()))
             check_targets(name, f, r.read_all(), d)
+
+
+@pytest.mark.parametrize("pipeline", [rt.RT_PIPELINE_WAVEFRONT, rt.RT_PIPELINE_MEGAKERNEL])
+def test_hip_matches_reference_glsl_taa_weight_regimes(pipeline):
+    """Frames 0, 1, 7, 8, 9, 31, 32, 33 of a 34-frame accumulation as the reference GLSL rendered them; the library takes uFrameIndex
+    from its own frame counter, so the frames in between are rendered too (their output is irrelevant: every checked frame gets
+    the reference's own history through rt_write_target)."""
+    d = np.load(GOLDEN / "glsl_bvh_taa_regimes_48x36.npz")
+    u0 = rt.RtUniforms.from_buffer_copy(d["uniforms0"].tobytes())
+    with rt.Renderer(pipeline=pipeline) as r:
+        r.resize(int(u0.resolution[0]), int(u0.resolution[1]))
+        r.upload_env(d["env"])
+        r.upload_bvh(d["nodes12"], d["tris12"])
+
+        def render(u, prev):
+            while r.frame_index < u.frameIndex:           # advance the frame counter to the fixture's frame
+                r.render_frame(u)
+            assert r.frame_index == u.frameIndex
+            if prev is not None:
+                r.write_target(rt.RT_TARGET_COLOR, prev)
+            r.render_frame(u)
+            return r.read_all()
+
+        check_taa_regimes(d, render)
 
 
 @pytest.mark.parametrize("tag", ["crate", "bunny"])
