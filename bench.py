@@ -85,6 +85,9 @@ def main():
     ap.add_argument("--size", default="1920x1080", help="framebuffer WxH (configs[3]: 3840x2160)")
     ap.add_argument("--spp", type=int, default=4, help="samples per pixel and frame (configs[2-3]: 16, configs[4]: 64)")
     ap.add_argument("--scene", default="bunny", choices=["bunny", "1m"], help="1m = configs[4]'s 1M-triangle multi-object scene")
+    ap.add_argument("--hybrid", action="store_true", help="EXTENSION (not in the reference; SURVEY 8d config 3 run B): the analytic scene "
+                    "(floor, glass / mirror / diffuse spheres) with the mesh added to it, reference default camera, megakernel")
+    ap.add_argument("--gi-bounces", type=int, default=1, help="EXTENSION: diffuse bounces of the analytic / hybrid GI path (configs[2]: 4)")
     args = ap.parse_args()
     global W, H, SPP
     W, H = (int(v) for v in args.size.lower().split("x"))
@@ -111,7 +114,6 @@ def main():
 
     pipeline = {"auto": rt.RT_PIPELINE_AUTO, "mega": rt.RT_PIPELINE_MEGAKERNEL, "wave": rt.RT_PIPELINE_WAVEFRONT}[args.pipeline]
     if args.scene == "1m":
-        import numpy as np
         v, fidx = rt.meshgen.million_triangle_scene()
         nodes, tris = rt.build_bvh(rt.gather_triangles(v, fidx, np.eye(4, dtype=np.float32).reshape(-1)))
     else:
@@ -130,10 +132,12 @@ def main():
         r.upload_bvh(nodes, tris)
         r.upload_env(faces)
         r.resize(W, H)
+        if args.gi_bounces != 1:
+            r.set_extension(gi_bounces=args.gi_bounces)
         return r
 
     def uniforms(cam, frame):
-        return rt.frame_uniforms(params, cam, W, H, frame, True, nodes.shape[0], tris.shape[0])
+        return rt.frame_uniforms(params, cam, W, H, frame, rt.RT_SCENE_HYBRID if args.hybrid else True, nodes.shape[0], tris.shape[0])
 
     def run_camera(cam, steps, warmup, timed_stage=True):
         """-> dict(ms_per_step, counters summed over the timed frames (this rank), stage times)"""
@@ -215,11 +219,17 @@ def main():
         return {"seconds": float(tt.item()), "counters": total, "local_counters": cnt, "stages": stages,
                 "traced_per_frame": traced_per_frame, "traced": traced, "scene_info": info, "counted_frames": steps}
 
-    closeup = run_camera(scenes.camera("closeup"), args.steps, args.warmup)
+    if args.hybrid:
+        # the mesh stands among the analytic objects, seen from the reference's default camera (include/app/state.h:129-131)
+        M = np.eye(4, dtype=np.float32)
+        M[0, 3], M[1, 3], M[2, 3] = -0.1, 1.0, -0.5
+        v_, f_ = rt.meshgen.bunny_standin(args.subdiv)
+        nodes, tris = rt.build_bvh(rt.gather_triangles(v_, f_, M.T.reshape(-1)))
+    closeup = run_camera(scenes.camera("default" if args.hybrid else "closeup"), args.steps, args.warmup)
     # serial stage breakdown (one frame in flight): in the timed run up to 3-4 frames overlap, which stretches every kernel's
     # wall span; this untimed pass shows what each stage costs when it has the GPU to itself
     serial_stages = None
-    if world == 1:
+    if world == 1 and not args.hybrid:
         old_lanes = os.environ.get("RT_LANES")
         os.environ["RT_LANES"] = "1"
         try:
@@ -324,6 +334,7 @@ def main():
                                  "kernel's own count over-states its TCP accesses by ~1.4x: profiles/README.md gives the PMC figure"}
         roofline = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                    "traffic_frac_of_peak": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                     "avg_launch_ms": avg_ms, "launches": launches, "algorithmic_bytes_per_launch": bytes_per_launch,
                     "attribution": attribution,
                     "bvh_bytes": {"nodes_2wide": info.bytesNodes2, "nodes_4wide": info.bytesNodes4, "triangle_pairs": info.bytesPairs},
@@ -336,14 +347,18 @@ def main():
                             "path (l1_gather), see DESIGN.md 4.3"}
 
     out = {
-        "metric": "Mray/s @1080p 4spp bunny BVH" if (args.scene, W, H, SPP) == ("bunny", 1920, 1080, 4) else "Mray/s @%dx%d %dspp %s BVH" % (W, H, SPP, args.scene),
+        "metric": "Mray/s @1080p 4spp bunny BVH" if (args.scene, W, H, SPP, args.hybrid) == ("bunny", 1920, 1080, 4, False) else
+                  "Mray/s @%dx%d %dspp %s%s" % (W, H, SPP, args.scene, " + analytic scene, %d GI bounces (extension, not in the reference)" % args.gi_bounces if args.hybrid else " BVH"),
         "value": mray, "unit": "Mray/s", "value_traversed": res["traced_per_frame"] * args.steps / res["seconds"] / 1e6,
         "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": ("configs[1]: " if (args.scene, W, H, SPP) == ("bunny", 1920, 1080, 4) else "variant: ")
                                + ("procedural bunny stand-in (icosphere subdiv %d" % args.subdiv if args.scene == "bunny" else "1M-triangle multi-object scene (")
-                               + ", %d tris, median-split BVH), %dx%d, %d spp, GI 1 bounce + AO 4, Sky_01 env, close-up camera (-2,1.5,1.0)" % (tris.shape[0], W, H, SPP),
+                               + (", %d tris, median-split BVH), %dx%d, %d spp, GI 1 bounce + AO 4, Sky_01 env, close-up camera (-2,1.5,1.0)" % (tris.shape[0], W, H, SPP)
+                                  if not args.hybrid else
+                                  ", %d tris) inside the reference's analytic scene (floor, diffuse / glass / mirror spheres, light marker) -- EXTENSION mode=hybrid, "
+                                  "not expressible in the reference -- %dx%d, %d spp, %d GI bounces + AO 4, Sky_01 env, reference default camera, megakernel" % (tris.shape[0], W, H, SPP, args.gi_bounces)),
                    "pipeline": args.pipeline, "tiles": "16x16 round-robin over ranks" if world > 1 else "single GPU",
                    "gather": gather_path if multi else None,
                    "rays_per_frame": rays // args.steps, "msample_per_s": npix * SPP * args.steps / res["seconds"] / 1e6,
@@ -360,7 +375,7 @@ def main():
     if serial_stages:
         out["stage_ms_per_frame_one_frame_in_flight"] = serial_stages
 
-    if not args.no_default_camera:
+    if not args.no_default_camera and not args.hybrid:
         d = run_camera(scenes.camera("default"), args.steps, args.warmup, timed_stage=False)
         out["default_camera"] = {"value": d["counters"].rays / d["seconds"] / 1e6, "unit": "Mray/s",
                                  "ms_per_step": d["seconds"] / args.steps * 1e3, "rays_per_frame": d["counters"].rays // args.steps,
@@ -370,7 +385,7 @@ def main():
         import tempfile
         import oracle as orc
         cores = usable_cores()
-        cam = scenes.camera("closeup")
+        cam = scenes.camera("default" if args.hybrid else "closeup")
         u = uniforms(cam, args.warmup)
         # the oracle's traversal + shade loop compiled -O3 -march=native on THIS host (bit-identical to the -O2 checker
         # build: tests/test_oracle_kat.py), (a) one thread -- the scalar figure the >= 10x target refers to -- (b) all usable cores.
@@ -383,7 +398,7 @@ def main():
                 for y in order:
                     for y0 in range(y, min(y + 16, H), rows):
                         t0 = time.perf_counter()
-                        _, c1 = orc.render(u, nodes, tris, faces, None, region=(0, y0, W, min(y0 + rows, H)), nthreads=nthreads, L=Ln)
+                        _, c1 = orc.render(u, nodes, tris, faces, None, region=(0, y0, W, min(y0 + rows, H)), nthreads=nthreads, L=Ln, gi_bounces=args.gi_bounces)
                         dt += time.perf_counter() - t0
                         rays_cpu += c1.rays
                         bands += 1

@@ -173,6 +173,17 @@ int rt_render_frame(RtContext *ctx, const RtUniforms *u);
 int rt_render_ray(RtContext *ctx, const RtRenderParams *params, const RtCamera *cam, int useBVH, int showMotion,
                   const float *currView, const float *currProj);
 
+/* ---- EXTENSION, not in the reference (BASELINE configs[2-3] "bunny + glass + mirror ..., 4 bounces": the reference's
+ * BVH mode has neither analytic objects nor materials, rt.frag:84-106).  RtUniforms.useBVH == RT_SCENE_HYBRID renders the ANALYTIC
+ * branch of rt.frag (:108-163) with the uploaded BVH mesh added to the analytic scene as one more object (material id 5: the default
+ * branch of getMaterial, rt_materials.glsl:123-124), so the glass sphere refracts it, the mirror reflects it, it casts and receives
+ * shadows, AO and GI.  giBounces > 1 lengthens the analytic GI path (oneBounceGIAnalytic) to that many diffuse bounces.  With an empty
+ * BVH and giBounces == 1 this is the reference's analytic mode bit for bit.  Parity: this repository's own oracle only.
+ * Megakernel pipeline. */
+#define RT_SCENE_HYBRID 2
+typedef struct RtExtension { int32_t giBounces; int32_t reserved[3]; } RtExtension;
+int rt_set_extension(RtContext *ctx, const RtExtension *ext);   /* applies to the frames rendered after the call */
+
 int rt_synchronize(RtContext *ctx);
 
 /* Read one render target of the last frame into host memory: full width x height image, row 0 =

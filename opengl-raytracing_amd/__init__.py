@@ -137,6 +137,13 @@ class RtSceneInfo(_Struct):
                [(n, C.c_uint64) for n in ("bytesNodes2", "bytesNodes4", "bytesPairs", "bytesTris")]
 
 
+class RtExtension(_Struct):
+    _fields_ = _fields([("giBounces", i32), ("reserved", (i32, 3))])
+
+
+RT_SCENE_HYBRID = 2   # RtUniforms.useBVH: the analytic scene + the BVH mesh (extension, not in the reference)
+
+
 class RtPresentParams(_Struct):  # uniforms of shaders/rt/rt_present.frag:38-50
     _fields_ = _fields([("exposure", f32), ("showMotion", i32), ("motionScale", f32), ("resolution", (f32, 2)), ("varMax", f32), ("kVar", f32),
                         ("kColor", f32), ("kVarMotion", f32), ("kColorMotion", f32), ("svgfStrength", f32), ("enableSVGF", i32)])
@@ -166,6 +173,7 @@ SIGNATURES = {
     "rt_frame_index": (C.c_int, [C.c_void_p]),
     "rt_render_frame": (C.c_int, [C.c_void_p, C.POINTER(RtUniforms)]),
     "rt_render_ray": (C.c_int, [C.c_void_p, C.POINTER(RtRenderParams), C.POINTER(RtCamera), C.c_int, C.c_int, _FP, _FP]),
+    "rt_set_extension": (C.c_int, [C.c_void_p, C.POINTER(RtExtension)]),
     "rt_synchronize": (C.c_int, [C.c_void_p]),
     "rt_read_target": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "rt_write_target": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
@@ -498,6 +506,11 @@ class Renderer:
         p = None if proj is None else _f32(proj)
         self._check(lib().rt_render_ray(self._h, C.byref(params), C.byref(cam), int(use_bvh), int(show_motion),
                                         None if v is None else _fp(v), None if p is None else _fp(p)))
+
+    def set_extension(self, gi_bounces=1):
+        """EXTENSION (not in the reference): bounces of the analytic / hybrid GI path."""
+        e = RtExtension(giBounces=int(gi_bounces))
+        self._check(lib().rt_set_extension(self._h, C.byref(e)))
 
     def synchronize(self):
         self._check(lib().rt_synchronize(self._h))

@@ -64,6 +64,7 @@ struct RtContext {
     void *dStaging = nullptr;
     size_t stagingBytes = 0;
     RtWave *wave[RT_MAX_LANES] = {};
+    int giBounces = 1;   // EXTENSION, rt_set_extension
     // tile-parallel exchange owned by the library (rt_comm.cpp): RCCL communicator + per-lane gather buffers on the gathering rank
     void *comm = nullptr;                               // ncclComm_t
     void *dGathered[RT_MAX_LANES][4] = {};              // [lane][target]: worldSize blocks, rank-major
@@ -631,7 +632,7 @@ int rt_render_frame(RtContext *c, const RtUniforms *uIn) {
     fr.u.frameIndex = c->frameIndex;
     if ((int)fr.u.resolution[0] != c->g.W || (int)fr.u.resolution[1] != c->g.H)
         return fail(c, RT_ERR_INVALID, "rt_render_frame: uResolution %gx%g != framebuffer %dx%d", fr.u.resolution[0], fr.u.resolution[1], c->g.W, c->g.H);
-    if (fr.u.useBVH == 1 && fr.u.nodeCount > 0 && fr.u.triCount > 0 && (c->nNodes == 0 || fr.u.nodeCount > c->nNodes || fr.u.triCount > c->nTris))
+    if ((fr.u.useBVH == 1 || fr.u.useBVH == RT_SCENE_HYBRID) && fr.u.nodeCount > 0 && fr.u.triCount > 0 && (c->nNodes == 0 || fr.u.nodeCount > c->nNodes || fr.u.triCount > c->nTris))
         return fail(c, RT_ERR_STATE, "rt_render_frame: uniforms name %d nodes / %d tris, uploaded %d / %d", fr.u.nodeCount, fr.u.triCount, c->nNodes, c->nTris);
     if (fr.u.useEnvMap == 1 && !c->dEnv) return fail(c, RT_ERR_STATE, "rt_render_frame: uUseEnvMap without an environment");
     const int prevLaneX = (c->writeIdx + c->nLanes - 1) % c->nLanes;
@@ -642,6 +643,7 @@ int rt_render_frame(RtContext *c, const RtUniforms *uIn) {
     fr.sc = make_dev_scene(c);
     if (!(fr.u.nodeCount > 0 && fr.u.triCount > 0)) fr.sc.hasBVH = 0;
     fr.g = c->g;
+    fr.giBounces = c->giBounces;
     // Lane = frame index mod nLanes = index of the COLOR0 buffer this frame writes: consecutive frames rotate over the lanes'
     // streams and overlap everywhere except at the temporal resolve (the only read of the previous frame), and every later
     // reader of a COLOR0 buffer (gather, assemble) is stream-ordered before the next writer of the same buffer.
@@ -692,6 +694,13 @@ int rt_render_ray(RtContext *c, const RtRenderParams *params, const RtCamera *ca
     int rc = rt_render_frame(c, &u);
     if (rc != RT_OK) return rc;
     std::memcpy(c->prevVP, VP, 64);                          // FrameState::endFrame, frame_state.h:81-84
+    return RT_OK;
+}
+
+int rt_set_extension(RtContext *c, const RtExtension *ext) {
+    if (!c || !ext) return RT_ERR_INVALID;
+    if (ext->giBounces < 1 || ext->giBounces > 8) return fail(c, RT_ERR_INVALID, "rt_set_extension: giBounces = %d (1..8)", ext->giBounces);
+    c->giBounces = ext->giBounces;
     return RT_OK;
 }
 

@@ -121,6 +121,7 @@ int main(int argc, char **argv) {
     bool dumpTargets = false;
     float dt = 1.0f / 60.0f;   // seconds per frame for the point-light orbit
     int W = 1920, H = 1080, frames = 1, device = 0, useBVH = 0, showMotion = 0;
+    int giBounces = 1;
     int ranks = 0, gatherEvery = 1;          // ranks 0 = plain single-process run without a communicator
     std::vector<int> devices;
     RtRenderParams params;
@@ -142,13 +143,15 @@ int main(int argc, char **argv) {
             for (const auto &kv : root.obj) {
                 const std::string &k = kv.first; const scenefile::Value &v = kv.second;
                 bool ok = true;
-                if (k == "obj") { useBVH = 1; if (v.kind == scenefile::Value::Str) objs.push_back(v.str); else if (v.kind == scenefile::Value::Arr) for (const auto &e : v.arr) { ok = ok && e.kind == scenefile::Value::Str; objs.push_back(e.str); } else ok = false; }
+                if (k == "obj") { if (useBVH == 0) useBVH = 1; if (v.kind == scenefile::Value::Str) objs.push_back(v.str); else if (v.kind == scenefile::Value::Arr) for (const auto &e : v.arr) { ok = ok && e.kind == scenefile::Value::Str; objs.push_back(e.str); } else ok = false; }
                 else if (k == "env") { ok = v.kind == scenefile::Value::Str; env = v.str; }
                 else if (k == "out") { ok = v.kind == scenefile::Value::Str; out = v.str; }
                 else if (k == "size") { ok = v.kind == scenefile::Value::Arr && v.arr.size() == 2; if (ok) { W = (int)v.arr[0].num; H = (int)v.arr[1].num; } }
                 else if (k == "frames") frames = (int)v.num;
                 else if (k == "dt") dt = (float)v.num;
                 else if (k == "bvh") useBVH = v.num != 0;
+                else if (k == "hybrid") { if (v.num != 0) useBVH = RT_SCENE_HYBRID; }
+                else if (k == "giBounces") giBounces = (int)v.num;
                 else if (k == "motion") showMotion = v.num != 0;
                 else if (k == "camera") {
                     ok = v.kind == scenefile::Value::Obj;
@@ -164,7 +167,7 @@ int main(int argc, char **argv) {
                 if (!ok) { std::fprintf(stderr, "rt_cli: %s: bad or unknown key \"%s\"\n", argv[i], k.c_str()); return 2; }
             }
         }
-        else if (a == "--obj") { objs.push_back(next()); useBVH = 1; }
+        else if (a == "--obj") { objs.push_back(next()); if (useBVH == 0) useBVH = 1; }
         else if (a == "--dump-targets") dumpTargets = true;
         else if (a == "--dt") dt = (float)std::atof(next());
         else if (a == "--env") env = next();
@@ -178,6 +181,8 @@ int main(int argc, char **argv) {
         else if (a == "--devices") { std::stringstream ss(next()); std::string t; while (std::getline(ss, t, ',')) devices.push_back(std::atoi(t.c_str())); }
         else if (a == "--bvh") useBVH = 1;
         else if (a == "--analytic") useBVH = 0;
+        else if (a == "--hybrid") useBVH = RT_SCENE_HYBRID;          // EXTENSION: analytic scene + the mesh (include/rt_mi355.h)
+        else if (a == "--gi-bounces") giBounces = std::atoi(next());  // EXTENSION: bounces of the analytic / hybrid GI path
         else if (a == "--motion") showMotion = 1;
         else if (a == "--no-gi") params.enableGI = 0;
         else if (a == "--no-ao") params.enableAO = 0;
@@ -190,6 +195,7 @@ int main(int argc, char **argv) {
         else if (a == "--aspect") { cam.aspect = (float)std::atof(next()); aspectSet = true; }
         else { std::fprintf(stderr, "usage: rt_cli [--obj f.obj] [--env cross.png] [--size WxH] [--spp n] [--frames n] [--bvh|--analytic] [--motion]\n"
                                     "              [--cam x,y,z,yaw,pitch] [--fov deg] [--aspect a] [--exposure e] [--no-gi --no-ao --no-taa --no-svgf --no-env] [--out prefix]\n"
+                                    "              [--hybrid [--gi-bounces n]]   EXTENSION: the analytic scene with the .obj mesh added to it, n diffuse GI bounces\n"
                                     "              [--ranks N [--devices d0,d1,..] [--gather-every k]]   tile-parallel over N GPUs, one process each, RCCL gather to rank 0\n"
                                     "              (--obj may be repeated; --dump-targets writes prefix_{color,motion,gpos,gnrm}.pfm; --scene file.json sets any of\n"
                                     "               the above and every RenderParams field by name)\n"); return a == "--help" ? 0 : 2; }
@@ -282,6 +288,7 @@ int main(int argc, char **argv) {
         else RT_SAY("[ENV] %s: 6 x %dx%d\n", env.c_str(), n, n);
     }
     if ((rc = rt_resize(ctx, W, H)) != RT_OK) die(ctx, "rt_resize", rc);
+    if (giBounces != 1) { RtExtension ext{}; ext.giBounces = giBounces; if ((rc = rt_set_extension(ctx, &ext)) != RT_OK) die(ctx, "rt_set_extension", rc); }
 
     const auto t0 = std::chrono::steady_clock::now();
     for (int f = 0; f < frames; ++f) {

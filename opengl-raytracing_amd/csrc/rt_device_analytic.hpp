@@ -9,7 +9,8 @@
 
 namespace rtd {
 
-enum { MAT_FLOOR = 0, MAT_ALBEDO_SPHERE = 1, MAT_GLASS_SPHERE = 2, MAT_MIRROR_SPHERE = 3, MAT_POINTLIGHT_SPHERE = 4 };
+enum { MAT_FLOOR = 0, MAT_ALBEDO_SPHERE = 1, MAT_GLASS_SPHERE = 2, MAT_MIRROR_SPHERE = 3, MAT_POINTLIGHT_SPHERE = 4,
+       MAT_MESH = 5 };   // EXTENSION (hybrid scene): no material of rt_materials.glsl -> getMaterial's default branch (:123-124)
 
 RT_DEV MaterialProps mkMat(V3 albedo, float spec, float gloss, int type, float ior) {
     MaterialProps m;
@@ -76,6 +77,27 @@ __device__ __noinline__ bool traceAnalyticCore(const RtUniforms &u, V3 ro, V3 rd
     return hit.t < u.inf;
 }
 
+// Scene query of the analytic shading code.  Reference modes: traceAnalyticCore.  EXTENSION uUseBVH == RT_SCENE_HYBRID (SURVEY.md 8d
+// config 3 "run B"): the BVH mesh is one more object at the end of the list, under the list's own rule (strict <: an earlier object
+// wins a tie); its hit is what traceBVH returns (geometric normal), its material id MAT_MESH.
+template <bool COUNT>
+__device__ __noinline__ bool traceScene(const Frag &F, V3 ro, V3 rd, bool includeGlass, bool includeMarker, Hit &hit, Work &w) {
+    const RtUniforms &u = *F.u;
+    bool any = traceAnalyticCore<COUNT>(u, ro, rd, includeGlass, includeMarker, hit, w);
+    if (u.useBVH == RT_SCENE_HYBRID && F.stk) {
+        float t;
+        int tri;
+        if (bvh_closest<COUNT>(*F.sc, ro, rd, u.eps, u.inf, F.stk, t, tri, w) && t < hit.t) {
+            hit.t = t;
+            hit.p = ro + rd * t;
+            hit.n = tri_normal(*F.sc, tri);
+            hit.mat = MAT_MESH;
+            any = true;
+        }
+    }
+    return any;
+}
+
 // directLight, rt_lighting.glsl:313-395 (analytic occlusion branch of occludedToward :55-58,
 // sunDirect :133-135, pointDirect :203-205).
 template <bool COUNT>
@@ -102,7 +124,7 @@ __device__ __noinline__ V3 directLightA(const Frag &F, const Hit &h, int frame, 
     for (int i = 0; i < 4; ++i) {
         DiskSample s = diskSample(F, h.p, N, frame, i, rot, lt, lb);
         Hit hh;
-        bool occ = traceAnalyticCore<COUNT>(u, s.ro, s.rd, true, true, hh, w) && hh.t < s.tMax;
+        bool occ = traceScene<COUNT>(F, s.ro, s.rd, true, true, hh, w) && hh.t < s.tMax;
         float vis = occ ? 0.0f : 1.0f;
         V3 Li = mk3(18.0f) * s.geom * vis;
         sum = sum + shadeLambertPhong(u.pi, N, V, s.L, Li, mat.albedo, mat.specStrength, mat.gloss);
@@ -118,7 +140,7 @@ __device__ __noinline__ V3 directLightA(const Frag &F, const Hit &h, int frame, 
             float e = epsForDist(1000.0f);
             V3 origin = h.p + N * e;
             Hit tmp;
-            bool blocked = traceAnalyticCore<COUNT>(u, origin, L, true, true, tmp, w);
+            bool blocked = traceScene<COUNT>(F, origin, L, true, true, tmp, w);
             if (!blocked) {
                 float specStrength = (mat.type == 0) ? mat.specStrength : 0.0f;
                 sun = shadeLambertPhong(u.pi, N, Vs, L, ld3(u.sunColor) * u.sunIntensity, mat.albedo, specStrength, mat.gloss);
@@ -141,7 +163,7 @@ __device__ __noinline__ V3 directLightA(const Frag &F, const Hit &h, int frame, 
                 float e = epsForDist(dist);
                 V3 origin = h.p + L * e;
                 Hit tmp;
-                bool blocked = traceAnalyticCore<COUNT>(u, origin, L, true, false, tmp, w) && tmp.t < dist - e;
+                bool blocked = traceScene<COUNT>(F, origin, L, true, false, tmp, w) && tmp.t < dist - e;
                 if (!blocked) {
                     V3 Li = ld3(u.pointLightColor) * (u.pointLightIntensity / fmaxr(dist2, 1e-4f));
                     float specStrength = (mat.type == 0) ? mat.specStrength : 0.0f;
@@ -154,21 +176,38 @@ __device__ __noinline__ V3 directLightA(const Frag &F, const Hit &h, int frame, 
     return sum;
 }
 
+// oneBounceGIAnalytic, rt_lighting.glsl:473-507, generalised to F.giBounces diffuse bounces (EXTENSION; giBounces == 1 -- the default
+// and all the reference does -- is that function operation for operation: 1 * x and 0 + x are exact).  Level k starts at hit h_k with
+// seed_k (seed_{k+1} = seed_k * 131 + 17, shadeMirror's derivation for its nested GI, :692) and throughput T_k (T_0 = 1):
+//   F = albedo(h_k) * (cos / pi);  Li = directLight(h_{k+1}) if the bounce ray hits, else sky(wi) and the path ends;
+//   result += (T_k * F) * Li;   T_{k+1} = (T_k * F) * giScaleAnalytic.           Same operations, same order as the parity checker's CPU restatement.
+constexpr int kMaxGiBounces = 8;
 template <bool COUNT>
-__device__ __noinline__ V3 oneBounceGIAnalytic(const Frag &F, const Hit &h0, int frame, int seed, Work &w) {   // :473-507
+__device__ __noinline__ V3 oneBounceGIAnalytic(const Frag &F, const Hit &h0, int frame, int seed, Work &w) {
     const RtUniforms &u = *F.u;
-    MaterialProps mat0 = getMaterial(u, h0.mat);
-    V3 N0 = normalize(h0.n);
-    float o13 = (float)(int)((uint32_t)seed * 13u), o37 = (float)(int)((uint32_t)seed * 37u);
-    V2 uu = mk2(randr(F.fcx + o13, F.fcy + o13, frame), randr(F.fcy + o37, F.fcx + o37, frame));
-    V3 wi = sampleHemisphereCosine(u.pi, N0, uu);
-    float cosTheta = fmaxr(dot(N0, wi), 0.0f);
-    if (cosTheta <= 0.0f) return mk3(0.0f);
-    V3 origin = h0.p + N0 * u.eps;
-    Hit h1;
-    bool hit1 = traceAnalyticCore<COUNT>(u, origin, wi, true, true, h1, w);
-    V3 Li = hit1 ? directLightA<COUNT>(F, h1, frame, -wi, w) : sky<COUNT>(F, wi, w);
-    return mat0.albedo * (cosTheta / u.pi) * Li;
+    V3 result = mk3(0.0f), T = mk3(1.0f);
+    Hit h = h0;
+    const int maxB = min(max(F.giBounces, 1), kMaxGiBounces);
+    for (int k = 0; k < maxB; ++k) {
+        MaterialProps mat0 = getMaterial(u, h.mat);
+        V3 N0 = normalize(h.n);
+        float o13 = (float)(int)((uint32_t)seed * 13u), o37 = (float)(int)((uint32_t)seed * 37u);
+        V2 uu = mk2(randr(F.fcx + o13, F.fcy + o13, frame), randr(F.fcy + o37, F.fcx + o37, frame));
+        V3 wi = sampleHemisphereCosine(u.pi, N0, uu);
+        float cosTheta = fmaxr(dot(N0, wi), 0.0f);
+        if (cosTheta <= 0.0f) break;
+        V3 origin = h.p + N0 * u.eps;
+        Hit h1;
+        bool hit1 = traceScene<COUNT>(F, origin, wi, true, true, h1, w);
+        V3 Li = hit1 ? directLightA<COUNT>(F, h1, frame, -wi, w) : sky<COUNT>(F, wi, w);
+        V3 TF = T * (mat0.albedo * (cosTheta / u.pi));
+        result = result + TF * Li;
+        if (!hit1) break;
+        T = TF * u.giScaleAnalytic;
+        h = h1;
+        seed = (int)((uint32_t)seed * 131u + 17u);
+    }
+    return result;
 }
 
 template <bool COUNT>
@@ -186,7 +225,7 @@ RT_DEV V3 shadeGlass(const Frag &F, const Hit &h, V3 wo, const MaterialProps &ma
     V3 reflectLocal = reflectEnv;
     {
         Hit hRefl;
-        if (traceAnalyticCore<COUNT>(u, h.p + R * u.eps, R, false, true, hRefl, w)) {
+        if (traceScene<COUNT>(F, h.p + R * u.eps, R, false, true, hRefl, w)) {
             V3 V2v = normalize(camPos - hRefl.p);
             reflectLocal = directLightA<COUNT>(F, hRefl, frame, V2v, w);
         }
@@ -195,7 +234,7 @@ RT_DEV V3 shadeGlass(const Frag &F, const Hit &h, V3 wo, const MaterialProps &ma
     V3 straightCol;
     {
         Hit hS;
-        if (traceAnalyticCore<COUNT>(u, h.p + I * u.eps, I, false, true, hS, w)) {
+        if (traceScene<COUNT>(F, h.p + I * u.eps, I, false, true, hS, w)) {
             V3 V2v = normalize(camPos - hS.p);
             straightCol = directLightA<COUNT>(F, hS, frame, V2v, w);
         } else straightCol = sky<COUNT>(F, I, w);
@@ -208,7 +247,7 @@ RT_DEV V3 shadeGlass(const Frag &F, const Hit &h, V3 wo, const MaterialProps &ma
         V3 T = normalize(mix(I, T_phys, distortionStrength));
         Hit hR;
         V3 bentCol;
-        if (traceAnalyticCore<COUNT>(u, h.p + T * u.eps, T, false, true, hR, w)) {
+        if (traceScene<COUNT>(F, h.p + T * u.eps, T, false, true, hR, w)) {
             V3 V2v = normalize(camPos - hR.p);
             bentCol = directLightA<COUNT>(F, hR, frame, V2v, w);
         } else bentCol = sky<COUNT>(F, T, w);
@@ -228,7 +267,7 @@ RT_DEV V3 shadeMirror(const Frag &F, const Hit &h, V3 wo, const MaterialProps &m
     V3 R = reflect(I, N);
     V3 org = h.p + R * u.eps;
     Hit h2;
-    bool hit2 = traceAnalyticCore<COUNT>(u, org, R, true, true, h2, w);
+    bool hit2 = traceScene<COUNT>(F, org, R, true, true, h2, w);
     V3 col;
     if (hit2) {
         col = directLightA<COUNT>(F, h2, frame, -R, w);
@@ -253,7 +292,7 @@ RT_DEV float computeAO_A(const Frag &F, const Hit &h, int frame, Work &w) {   //
         V3 dir = sampleHemisphereCosine(u.pi, N, uu);
         V3 org = h.p + N * u.aoBias;
         Hit tmp;
-        bool hitAny = traceAnalyticCore<COUNT>(u, org, dir, true, true, tmp, w);
+        bool hitAny = traceScene<COUNT>(F, org, dir, true, true, tmp, w);
         if (hitAny && tmp.t < u.aoRadius) occludedCount++;
     }
     float occ = (float)occludedCount / (float)u.aoSamples;

@@ -268,6 +268,10 @@ struct Frag {
     const RtUniforms *u;   // kernel-argument copy (uniform across the grid)
     const DevScene *sc;
     float fcx, fcy;        // gl_FragCoord.xy
+    // EXTENSION (hybrid scene, RT_SCENE_HYBRID): this lane's traversal stack, so that the analytic scene query can also walk the BVH;
+    // bounces of the analytic / hybrid GI path (1 = the reference).  Unused in the reference's two modes.
+    StackEntry *stk = nullptr;
+    int giBounces = 1;
 };
 
 // texture(uEnvMap, dir): face selection per the GL cube-map table, LINEAR, CLAMP_TO_EDGE, not seamless.

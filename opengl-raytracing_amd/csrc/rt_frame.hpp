@@ -24,6 +24,7 @@ struct DevFrame {   // one copy in HBM, refreshed per frame; kernels read it thr
     RtUniforms u;
     DevScene sc;
     FrameGeom g;
+    int giBounces;  // EXTENSION (rt_set_extension): bounces of the analytic / hybrid GI path, 1 = the reference
 };
 
 struct Targets {

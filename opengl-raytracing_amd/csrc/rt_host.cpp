@@ -326,7 +326,7 @@ void rt_make_uniforms(const RtRenderParams *p, const RtCamera *cam, const float 
         const float k = cameraMoved ? p->jitterMovingScale : p->jitterStillScale;
         u->jitter[0] = j[0] * k; u->jitter[1] = j[1] * k;
     }
-    u->useBVH = useBVH ? 1 : 0; u->nodeCount = nodeCount; u->triCount = triCount;
+    u->useBVH = useBVH == RT_SCENE_HYBRID ? RT_SCENE_HYBRID : (useBVH ? 1 : 0); u->nodeCount = nodeCount; u->triCount = triCount;   // render.cpp:94 sets app.useBVH ? 1 : 0; 2 = the hybrid extension
     u->showMotion = showMotion ? 1 : 0;
     std::memcpy(u->prevViewProj, prevVP, 64);
     std::memcpy(u->currViewProj, currVP, 64);

@@ -56,6 +56,8 @@ __global__ __launch_bounds__(256) void k_mega(const DevFrame *__restrict__ fr, T
     if (live) {
         Frag F;
         F.u = &u; F.sc = &fr->sc; F.fcx = (float)px + 0.5f; F.fcy = (float)py + 0.5f;
+        F.stk = &lds_stack[(tid >> 6) * STACK * 64 + (tid & 63)];
+        F.giBounces = fr->giBounces;
         const int SPP = max(u.spp, 1);
         const V3 camPos = ld3(u.camPos);
         const V3 dir = primaryDir(u, F.fcx, F.fcy);
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(256) void k_mega(const DevFrame *__restrict__ fr, T
             for (int s = 0; s < SPP; ++s) {
                 int seed = (int)((uint32_t)u.frameIndex * (uint32_t)SPP + (uint32_t)s);
                 Hit h;
-                bool hitAny = traceAnalyticCore<COUNT>(u, camPos, dir, true, true, h, w);
+                bool hitAny = traceScene<COUNT>(F, camPos, dir, true, true, h, w);   // the analytic scene (+ the mesh in the hybrid extension)
                 V3 radiance;
                 if (hitAny) {
                     if (s == 0) {

@@ -274,7 +274,7 @@ void orc_make_uniforms(const OrcRenderParams *p, const OrcCamera *cam, const flo
         u->jitter[0] = j[0] * scale; u->jitter[1] = j[1] * scale;
     }
     u->enableJitter = p->enableJitter ? 1 : 0;
-    u->useBVH = useBVH ? 1 : 0; u->nodeCount = nodeCount; u->triCount = triCount;
+    u->useBVH = useBVH == 2 ? 2 : (useBVH ? 1 : 0); u->nodeCount = nodeCount; u->triCount = triCount;   // render.cpp:94; 2 = the hybrid extension (rt_oracle.cpp kSceneHybrid)
     u->showMotion = showMotion ? 1 : 0;
     std::memcpy(u->prevViewProj, prevViewProj, 64);
     std::memcpy(u->currViewProj, currViewProj, 64);

@@ -44,7 +44,12 @@ struct Scene {
     int envSize = 0, envCh = 0;
     const uint16_t *prev = nullptr; // W*H*4 half, previous COLOR0
     int W = 0, H = 0;
+    int giBounces = 1;              // EXTENSION (not in the reference): diffuse bounces of the analytic / hybrid GI path, see giPath
 };
+// EXTENSION, not in the reference (SURVEY.md 8d config 3 "run B", labelled mode=hybrid): uUseBVH == 2 renders the analytic branch of
+// rt.frag with the BVH mesh added to the analytic scene as one more object.  Everything else is the reference's analytic code.
+static const int kSceneHybrid = 2;
+static const int MAT_MESH = 5;      // no material of rt_materials.glsl:20-24 -> getMaterial's default branch (:123-124): 0.8 grey, spec 0.2, gloss 16, diffuse
 
 // ---------------------------------------------------------------- rt_common.glsl
 struct Hit { float t; vec3 p; vec3 n; int mat; };                       // :39-44
@@ -163,6 +168,7 @@ static bool intersectSphere(const Scene &S, vec3 ro, vec3 rd, vec3 c, float r, H
     h.mat = matId;
     return true;
 }
+static bool traceBVH(const Scene &S, Counters &C, vec3 ro, vec3 rd, Hit &hitOut);
 static bool traceAnalyticCore(const Scene &S, Counters &C, vec3 ro, vec3 rd, bool includeGlass,
                               bool includePointLightSphere, Hit &hit) {                              // :132-167
     C.raysAnalytic++;
@@ -177,6 +183,11 @@ static bool traceAnalyticCore(const Scene &S, Counters &C, vec3 ro, vec3 rd, boo
     if (includePointLightSphere && S.u.pointLightEnabled == 1) {
         if (intersectSphere(S, ro, rd, ld3(S.u.pointLightPos), kPointLightRadius, h, MAT_POINTLIGHT_SPHERE) && h.t < hit.t)
             hit = h;
+    }
+    if (S.u.useBVH == kSceneHybrid) {
+        // EXTENSION: the mesh is the last object of the list, under the list's own rule (strict <: an earlier object wins a tie);
+        // its hit is what traceBVH returns (geometric normal), its material id the mesh's
+        if (traceBVH(S, C, ro, rd, h) && h.t < hit.t) { hit = h; hit.mat = MAT_MESH; }
     }
     return hit.t < S.u.inf;
 }
@@ -515,20 +526,38 @@ static vec3 directLightBVH(const Scene &S, Counters &C, const Frag &F, const Hit
     sum += pointDirect(S, C, h, fakeMat, V);
     return sum;
 }
-static vec3 oneBounceGIAnalytic(const Scene &S, Counters &C, const Frag &F, const Hit &h0, int frame, int seed) {   // :473-507
-    MaterialProps mat0 = getMaterial(S, h0.mat);
-    vec3 albedo0 = mat0.albedo;
-    vec3 N0 = normalize(h0.n);
-    float o13 = (float)(int)((uint32_t)seed * 13u), o37 = (float)(int)((uint32_t)seed * 37u);
-    vec2 u = {rand_(vec2{F.fc.x + o13, F.fc.y + o13}, frame), rand_(vec2{F.fc.y + o37, F.fc.x + o37}, frame)};
-    vec3 wi = sampleHemisphereCosine(S, N0, u);
-    float cosTheta = fmax_(dot(N0, wi), 0.0f);
-    if (cosTheta <= 0.0f) return v3(0.0f);
-    vec3 origin = h0.p + N0 * S.u.eps;
-    Hit h1;
-    bool hit1 = traceAnalytic(S, C, origin, wi, h1);
-    vec3 Li = hit1 ? directLight(S, C, F, h1, frame, -wi) : sky(S, C, wi);
-    return albedo0 * (cosTheta / S.u.pi) * Li;
+// oneBounceGIAnalytic, rt_lighting.glsl:473-507, generalised to S.giBounces diffuse bounces (EXTENSION; with giBounces == 1 --
+// the default and the only thing the reference does -- this is that function, operation for operation: 1 * x and 0 + x are exact).
+// Level k = 0, 1, ... starts at hit h_k with seed_k (seed_{k+1} = seed_k * 131 + 17, the derivation shadeMirror uses for its nested
+// GI, :692) and throughput T_k (T_0 = 1):
+//   F = albedo(h_k) * (cos / pi);  Li = directLight(h_{k+1}) if the bounce ray hits, else sky(wi) and the path ends;
+//   result += (T_k * F) * Li;   T_{k+1} = (T_k * F) * giScaleAnalytic.
+// The device code (csrc/rt_device_analytic.hpp) performs the same operations in the same order.
+static const int kMaxGiBounces = 8;
+static vec3 oneBounceGIAnalytic(const Scene &S, Counters &C, const Frag &F, const Hit &h0, int frame, int seed) {
+    vec3 result = v3(0.0f), T = v3(1.0f);
+    Hit h = h0;
+    const int maxB = S.giBounces < 1 ? 1 : (S.giBounces > kMaxGiBounces ? kMaxGiBounces : S.giBounces);
+    for (int k = 0; k < maxB; ++k) {
+        MaterialProps mat0 = getMaterial(S, h.mat);
+        vec3 N0 = normalize(h.n);
+        float o13 = (float)(int)((uint32_t)seed * 13u), o37 = (float)(int)((uint32_t)seed * 37u);
+        vec2 u = {rand_(vec2{F.fc.x + o13, F.fc.y + o13}, frame), rand_(vec2{F.fc.y + o37, F.fc.x + o37}, frame)};
+        vec3 wi = sampleHemisphereCosine(S, N0, u);
+        float cosTheta = fmax_(dot(N0, wi), 0.0f);
+        if (cosTheta <= 0.0f) break;
+        vec3 origin = h.p + N0 * S.u.eps;
+        Hit h1;
+        bool hit1 = traceAnalytic(S, C, origin, wi, h1);
+        vec3 Li = hit1 ? directLight(S, C, F, h1, frame, -wi) : sky(S, C, wi);
+        vec3 TF = T * (mat0.albedo * (cosTheta / S.u.pi));
+        result = result + TF * Li;
+        if (!hit1) break;
+        T = TF * S.u.giScaleAnalytic;
+        h = h1;
+        seed = (int)((uint32_t)seed * 131u + 17u);
+    }
+    return result;
 }
 static vec3 oneBounceGIBVH(const Scene &S, Counters &C, const Frag &F, const Hit &h0, int frame, int seed) {   // :515-561
     const vec3 albedo0 = v3(0.85f);
@@ -838,6 +867,10 @@ int orc_trace_bvh_shadow(const OrcUniforms *u, const float *nodes, const float *
 // Render the pixel rectangle [x0,x1) x [y0,y1) of one frame. Targets are full W x H arrays, row 0 =
 // bottom row (glReadPixels order), RGBA16F / RG16F / RGBA16F / RGBA16F as half bit patterns.
 // pixelMask (optional, W*H bytes): only pixels with a non-zero byte are shaded (tile-parallel tests).
+// EXTENSION knob (see Scene::giBounces): bounces of the analytic / hybrid GI path for the orc_render calls that follow.  1 = the reference.
+static std::atomic<int> g_giBounces{1};
+void orc_set_gi_bounces(int n) { g_giBounces = n; }
+
 int orc_render(const OrcUniforms *u, const float *nodes12, const float *tris12, const uint8_t *envFaces, int envFaceSize,
                int envChannels, const uint16_t *prevAccum, uint16_t *outColor, uint16_t *outMotion, uint16_t *outGPos,
                uint16_t *outGNrm, int x0, int y0, int x1, int y1, const uint8_t *pixelMask, int nthreads, OrcCounters *counters) {
@@ -846,10 +879,11 @@ int orc_render(const OrcUniforms *u, const float *nodes12, const float *tris12, 
     S.nodes = nodes12; S.tris = tris12;
     S.env = envFaces; S.envSize = envFaceSize; S.envCh = envChannels;
     S.prev = prevAccum;
+    S.giBounces = g_giBounces;
     S.W = (int)u->resolution[0]; S.H = (int)u->resolution[1];
     if (S.W <= 0 || S.H <= 0) return -1;
     if (u->useEnvMap == 1 && (!envFaces || envFaceSize <= 0 || envChannels < 3)) return -2;
-    if (u->useBVH == 1 && u->nodeCount > 0 && u->triCount > 0 && (!nodes12 || !tris12)) return -3;
+    if ((u->useBVH == 1 || u->useBVH == kSceneHybrid) && u->nodeCount > 0 && u->triCount > 0 && (!nodes12 || !tris12)) return -3;
     x0 = std::max(x0, 0); y0 = std::max(y0, 0); x1 = std::min(x1, S.W); y1 = std::min(y1, S.H);
     if (nthreads < 1) nthreads = 1;
     std::atomic<int> nextRow{y0};
