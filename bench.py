@@ -353,7 +353,7 @@ def main():
         "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": ("configs[1]: " if (args.scene, W, H, SPP) == ("bunny", 1920, 1080, 4) else "variant: ")
+        "config": {"workload": ("configs[1]: " if (args.scene, W, H, SPP, args.hybrid) == ("bunny", 1920, 1080, 4, False) else "variant: ")
                                + ("procedural bunny stand-in (icosphere subdiv %d" % args.subdiv if args.scene == "bunny" else "1M-triangle multi-object scene (")
                                + (", %d tris, median-split BVH), %dx%d, %d spp, GI 1 bounce + AO 4, Sky_01 env, close-up camera (-2,1.5,1.0)" % (tris.shape[0], W, H, SPP)
                                   if not args.hybrid else
