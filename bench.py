@@ -99,6 +99,7 @@ def main():
     from opengl_raytracing_amd.dist_gather import FrameGatherer, NativeGatherer
     import scenes
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL between processes: before anything initialises HIP
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
