@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--pipeline", default="auto", choices=["auto", "mega", "wave"])
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of EACH oracle (CPU baseline) sample -- one thread, then all cores; 0 = skip")
     ap.add_argument("--no-default-camera", action="store_true")
+    ap.add_argument("--batch", type=int, default=8, help="frames per rt_render_frames call: consecutive frames of the static camera share one set of "
+                    "kernel launches (bit-identical to frame-by-frame rendering, tests/test_gpu_baseline_configs.py); 1 = one rt_render_frame per step")
     ap.add_argument("--gather-every", type=int, default=1, help="N > 1 GPUs: gather COLOR0 to rank 0 every k-th frame (1 = every frame; a static "
                     "camera's history is tile-local, so BASELINE configs[4] needs one gather per 32 accumulated frames)")
     ap.add_argument("--force-gather", action="store_true", help="rehearsal on one GPU: run the N > 1 code path (process group, communicator, "
@@ -124,7 +126,8 @@ def main():
     params.sppPerFrame = SPP
     npix = W * H
 
-    gather_path = {"path": "library-owned RCCL communicator (rt_comm_init / rt_gather_frame)", "gather_every": args.gather_every}
+    gather_path = {"path": "library-owned RCCL communicator (rt_comm_init / rt_gather_frame)", "gather_every": args.gather_every,
+                   "when": "after each batch of frames (its last frame), and after the last timed frame"}
 
     def make_renderer(count):
         # work counters (reference units) come from the reference-shaped megakernel; the timed run uses `pipeline`
@@ -167,26 +170,35 @@ def main():
                     ok.zero_()
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if args.gather != "native" or ok.item() == 0:
-                gatherer = FrameGatherer(ren)
+                gatherer = FrameGatherer(ren, gather_every=args.gather_every)
                 gather_path["path"] = "torch.distributed (RCCL) on the library's device pointers"
         # setup, not a step: every frame lane (3-4 streams with their own ray-queue arenas) allocates on its first frame; do that
         # before the W warm-up steps so that a small W cannot push a multi-GB hipMalloc into the timed region
-        for f in range(5):
-            ren.render_frame(uniforms(cam, f))
+        B = max(1, min(args.batch, 16))
+        setup_u = [uniforms(cam, f) for f in range(5 * B)]
+        for b in range(5):
+            ren.render_frames(setup_u[b * B:(b + 1) * B])
             if gatherer:
-                gatherer.gather()
+                gatherer.after(B, last=True)
         ren.synchronize()
         ren.reset_accum()
+        if gatherer:
+            gatherer.frames = 0
 
         frames_u = [uniforms(cam, f) for f in range(warmup + steps)]   # inputs prepared outside the timed region
 
-        def step(f):
-            ren.render_frame(frames_u[f])
-            if gatherer:
-                gatherer.gather()      # RCCL gather of COLOR0 to rank 0 + un-tiling kernel (every --gather-every-th frame), on the frame's stream
+        def run_steps(f0, f1):
+            """Frames f0..f1-1 in batches of B (the last one shorter): rt_render_frames, then -- tile-parallel -- the RCCL gather of COLOR0
+            to rank 0 + un-tiling kernel for the batch's last frame, if a --gather-every boundary was crossed (default: every batch)."""
+            f = f0
+            while f < f1:
+                n = min(B, f1 - f)
+                ren.render_frames(frames_u[f:f + n])
+                f += n
+                if gatherer:
+                    gatherer.after(n, last=(f == f1))
 
-        for f in range(warmup):
-            step(f)
+        run_steps(0, warmup)
         ren.synchronize()
         torch.cuda.synchronize()
         if timed_stage:
@@ -195,8 +207,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for f in range(warmup, warmup + steps):
-            step(f)
+        run_steps(warmup, warmup + steps)
         ren.synchronize()
         torch.cuda.synchronize()
         if multi:
@@ -230,20 +241,39 @@ def main():
     # serial stage breakdown (one frame in flight): in the timed run up to 3-4 frames overlap, which stretches every kernel's
     # wall span; this untimed pass shows what each stage costs when it has the GPU to itself
     serial_stages = None
+    unbatched_ms = None
     if world == 1 and not args.hybrid:
         old_lanes = os.environ.get("RT_LANES")
         os.environ["RT_LANES"] = "1"
         try:
             r1 = make_renderer(False)
             cam1 = scenes.camera("closeup")
-            for f in range(max(args.warmup, 2)):
-                r1.render_frame(uniforms(cam1, f))
+            B1 = max(1, min(args.batch, 16))
+            us1 = [uniforms(cam1, f) for f in range(4 * B1)]
+            r1.render_frames(us1[:B1])
+            r1.render_frames(us1[B1:2 * B1])
             r1.enable_stage_timing(True)
-            for f in range(max(args.warmup, 2), max(args.warmup, 2) + 8):
-                r1.render_frame(uniforms(cam1, f))
+            r1.render_frames(us1[2 * B1:3 * B1])
+            r1.render_frames(us1[3 * B1:])
             sst = r1.stage_times()
-            serial_stages = {k: v["ms"] / 8 for k, v in sst["stages"].items()}
+            serial_stages = {k: v["ms"] / (2 * B1) for k, v in sst["stages"].items()}
             r1.close()
+            # frame by frame (one rt_render_frame per step, three frames in flight), for comparison with the batched figure
+            del os.environ["RT_LANES"]
+            if old_lanes is not None:
+                os.environ["RT_LANES"] = old_lanes
+            r2 = make_renderer(False)
+            us2 = [uniforms(cam1, f) for f in range(48)]
+            for u2 in us2[:8]:
+                r2.render_frame(u2)
+            r2.synchronize()
+            t2 = time.perf_counter()
+            for u2 in us2[8:]:
+                r2.render_frame(u2)
+            r2.synchronize()
+            unbatched_ms = (time.perf_counter() - t2) / 40 * 1e3
+            r2.close()
+            os.environ["RT_LANES"] = "1"
         finally:
             if old_lanes is None:
                 del os.environ["RT_LANES"]
@@ -362,6 +392,10 @@ def main():
                                   "not expressible in the reference -- %dx%d, %d spp, %d GI bounces + AO 4, Sky_01 env, reference default camera, megakernel" % (tris.shape[0], W, H, SPP, args.gi_bounces)),
                    "pipeline": args.pipeline, "tiles": "16x16 round-robin over ranks" if world > 1 else "single GPU",
                    "gather": gather_path if multi else None,
+                   "frames_per_launch_set": max(1, min(args.batch, 16)),
+                   "batching": "rt_render_frames: consecutive frames of the static camera (they differ in uFrameIndex and uJitter only) share one set of "
+                               "kernel launches; every frame is fully rendered, results are bit-identical to one rt_render_frame per frame",
+                   "ms_per_step_frame_by_frame": unbatched_ms,
                    "rays_per_frame": rays // args.steps, "msample_per_s": npix * SPP * args.steps / res["seconds"] / 1e6,
                    "hit_pixels": res["counters"].hitPixels // args.steps,
                    "rays_traversed_per_frame": res["traced_per_frame"],

@@ -167,6 +167,13 @@ int rt_frame_index(const RtContext *ctx);
  * replaced by rt_frame_index().  Asynchronous on the context's stream. */
 int rt_render_frame(RtContext *ctx, const RtUniforms *u);
 
+/* `count` consecutive frames (us[i] = the uniform block of frame rt_frame_index() + i) with as few launches as possible: runs of
+ * frames that differ only in uJitter / uFrameIndex and have uCameraMoved == 0 -- an accumulating static camera, every BASELINE
+ * configuration -- are rendered up to 16 at a time by one set of kernel launches (BVH scenes, wavefront pipeline); anything else
+ * falls back to one rt_render_frame per frame.  Bit-identical to `count` calls of rt_render_frame; afterwards the four targets hold
+ * the last frame.  This is what keeps a tile-parallel rank busy: with 1/8 of the pixels a single frame is too little work per launch. */
+int rt_render_frames(RtContext *ctx, const RtUniforms *us, int count);
+
 /* The reference call-site in one call: mainLoop steps application.cpp:381-405 + renderRay + endFrame
  * (:459).  Keeps FrameState (prev/curr view-projection) inside the context.  currView/currProj may
  * be NULL: they are then derived from `cam` (Camera.cpp:66-73). */

@@ -172,6 +172,7 @@ SIGNATURES = {
     "rt_reset_accum": (C.c_int, [C.c_void_p]),
     "rt_frame_index": (C.c_int, [C.c_void_p]),
     "rt_render_frame": (C.c_int, [C.c_void_p, C.POINTER(RtUniforms)]),
+    "rt_render_frames": (C.c_int, [C.c_void_p, C.POINTER(RtUniforms), C.c_int]),
     "rt_render_ray": (C.c_int, [C.c_void_p, C.POINTER(RtRenderParams), C.POINTER(RtCamera), C.c_int, C.c_int, _FP, _FP]),
     "rt_set_extension": (C.c_int, [C.c_void_p, C.POINTER(RtExtension)]),
     "rt_synchronize": (C.c_int, [C.c_void_p]),
@@ -500,6 +501,11 @@ class Renderer:
 
     def render_frame(self, u: RtUniforms):
         self._check(lib().rt_render_frame(self._h, C.byref(u)))
+
+    def render_frames(self, us):
+        """Consecutive frames, batched into as few launches as possible (rt_render_frames); us: sequence of RtUniforms."""
+        arr = (RtUniforms * len(us))(*us)
+        self._check(lib().rt_render_frames(self._h, arr, len(us)))
 
     def render_ray(self, params, cam, use_bvh=False, show_motion=False, view=None, proj=None):
         v = None if view is None else _f32(view)

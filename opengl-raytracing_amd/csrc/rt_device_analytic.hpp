@@ -119,7 +119,7 @@ __device__ __noinline__ V3 directLightA(const Frag &F, const Hit &h, int frame, 
     }
     V3 lt, lb;
     lightFrame(lt, lb);
-    V2 rot = cpOffset(F.fcx, F.fcy, u.frameIndex);
+    V2 rot = cpOffset(F.fcx, F.fcy, F.frameIndex);
     V3 sum = mk3(0.0f);
     for (int i = 0; i < 4; ++i) {
         DiskSample s = diskSample(F, h.p, N, frame, i, rot, lt, lb);
@@ -314,8 +314,8 @@ RT_DEV V3 shadeSampleAnalytic(const Frag &F, const Hit &h, V3 V, int seed, Work 
         return baseCol * falloff;
     }
     V3 radiance = directLightA<COUNT>(F, h, seed, V, w);
-    if (u.enableGI == 1) radiance = radiance + u.giScaleAnalytic * oneBounceGIAnalytic<COUNT>(F, h, u.frameIndex, seed, w);
-    if (u.enableAO == 1) radiance = radiance * computeAO_A<COUNT>(F, h, u.frameIndex, w);
+    if (u.enableGI == 1) radiance = radiance + u.giScaleAnalytic * oneBounceGIAnalytic<COUNT>(F, h, F.frameIndex, seed, w);
+    if (u.enableAO == 1) radiance = radiance * computeAO_A<COUNT>(F, h, F.frameIndex, w);
     return radiance;
 }
 

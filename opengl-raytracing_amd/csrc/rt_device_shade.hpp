@@ -272,6 +272,9 @@ struct Frag {
     // bounces of the analytic / hybrid GI path (1 = the reference).  Unused in the reference's two modes.
     StackEntry *stk = nullptr;
     int giBounces = 1;
+    // uFrameIndex of THIS fragment's frame.  The reference's value for a single frame; with frame batching (rt_render_frames: K frames of
+    // a static camera in one set of launches) the frames of a batch differ in it -- and in the jitter, see primaryDirJ -- and in nothing else.
+    int frameIndex = 0;
 };
 
 // texture(uEnvMap, dir): face selection per the GL cube-map table, LINEAR, CLAMP_TO_EDGE, not seamless.
@@ -410,7 +413,7 @@ RT_DEV V3 directLightBVH(T &tr, const Frag &F, int seg, V3 hp, V3 hn, int frame,
     const float specStrength = 0.25f, gloss = 32.0f;
     V3 lt, lb;
     lightFrame(lt, lb);
-    V2 rot = cpOffset(F.fcx, F.fcy, u.frameIndex);
+    V2 rot = cpOffset(F.fcx, F.fcy, F.frameIndex);
     V3 V = normalize(Vdir);
     for (int i = 0; i < 4; ++i) {   // SOFT_SHADOW_SAMPLES
         DiskSample s = diskSample(F, hp, N, frame, i, rot, lt, lb);
@@ -511,7 +514,7 @@ template <class T, bool COUNT>
 RT_DEV V3 shadeSampleBVH(T &tr, const Frag &F, V3 hp, V3 hn, V3 V, int seed, float ao, Work &w) {
     const RtUniforms &u = *F.u;
     V3 radiance = directLightBVH(tr, F, SEG_DIRECT, hp, hn, seed, V);
-    if (u.enableGI == 1) radiance = radiance + u.giScaleBVH * oneBounceGIBVH<T, COUNT>(tr, F, hp, hn, u.frameIndex, seed, w);
+    if (u.enableGI == 1) radiance = radiance + u.giScaleBVH * oneBounceGIBVH<T, COUNT>(tr, F, hp, hn, F.frameIndex, seed, w);
     if (u.enableAO == 1) radiance = radiance * ao;
     return radiance;
 }
@@ -561,13 +564,14 @@ RT_DEV V4 resolveTAA(const RtUniforms &u, V3 curr, float uvx, float uvy, V2 moti
     return mk4(taaCol.x, taaCol.y, taaCol.z, m2New);
 }
 
-// Primary ray of rt.frag:58-68.
-RT_DEV V3 primaryDir(const RtUniforms &u, float fcx, float fcy) {
-    float jx = (u.enableJitter == 1) ? u.jitter[0] : 0.0f, jy = (u.enableJitter == 1) ? u.jitter[1] : 0.0f;
+// Primary ray of rt.frag:58-68.  (jitterX, jitterY) = uJitter of the fragment's frame.
+RT_DEV V3 primaryDirJ(const RtUniforms &u, float fcx, float fcy, float jitterX, float jitterY) {
+    float jx = (u.enableJitter == 1) ? jitterX : 0.0f, jy = (u.enableJitter == 1) ? jitterY : 0.0f;
     float uvx = (fcx + jx) / u.resolution[0], uvy = (fcy + jy) / u.resolution[1];
     float nx = uvx * 2.0f - 1.0f, ny = uvy * 2.0f - 1.0f;
     V3 camRight = ld3(u.camRight), camUp = ld3(u.camUp), camFwd = ld3(u.camFwd);
     return normalize(camFwd + (nx * camRight) * (u.tanHalfFov * u.aspect) + (ny * camUp) * u.tanHalfFov);
 }
+RT_DEV V3 primaryDir(const RtUniforms &u, float fcx, float fcy) { return primaryDirJ(u, fcx, fcy, u.jitter[0], u.jitter[1]); }
 
 }  // namespace rtd

@@ -16,8 +16,13 @@
 
 namespace rtd {
 
+#define RT_MAX_BATCH 16
 struct FrameGeom {
     int W, H, tilesX, tilesY, nTiles, rank, world, nLocalTiles;
+    // Frame batching (rt_render_frames): `batch` consecutive frames of a static camera share one set of launches.  The kernels see
+    // batch x nLocalTiles "local tiles": local tile index lt' = k * nLocalTiles + lt is tile lt of the batch's k-th frame, and pixel
+    // slots follow (slot' = lt' * 256 + tid).  batch == 1 is the plain single frame.
+    int batch;
 };
 
 struct DevFrame {   // one copy in HBM, refreshed per frame; kernels read it through scalar loads
@@ -25,6 +30,7 @@ struct DevFrame {   // one copy in HBM, refreshed per frame; kernels read it thr
     DevScene sc;
     FrameGeom g;
     int giBounces;  // EXTENSION (rt_set_extension): bounces of the analytic / hybrid GI path, 1 = the reference
+    float jitterK[RT_MAX_BATCH][2];   // uJitter of the batch's frames (frame k has uFrameIndex = u.frameIndex + k); [0] == u.jitter
 };
 
 struct Targets {
@@ -37,7 +43,13 @@ struct Targets {
     uint2 *gnrm;         // COLOR3 RGBA16F
 };
 
+RT_DEV int sub_frame_of_tile(const FrameGeom &g, int localTile) { return g.batch > 1 ? localTile / max(g.nLocalTiles, 1) : 0; }
+RT_DEV int sub_frame_of_slot(const FrameGeom &g, uint32_t slot) { return sub_frame_of_tile(g, (int)(slot >> 8)); }
 RT_DEV bool pixel_of_slot(const FrameGeom &g, int localTile, int tid, int &x, int &y) {
+    if (g.batch > 1) {
+        if (localTile >= g.nLocalTiles * g.batch) { x = y = 0; return false; }
+        localTile %= max(g.nLocalTiles, 1);
+    }
     int t = localTile * g.world + g.rank;
     int tx = t % g.tilesX, ty = t / g.tilesX;
     int q = tid >> 6, lane = tid & 63;

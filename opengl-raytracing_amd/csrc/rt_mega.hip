@@ -58,6 +58,7 @@ __global__ __launch_bounds__(256) void k_mega(const DevFrame *__restrict__ fr, T
         F.u = &u; F.sc = &fr->sc; F.fcx = (float)px + 0.5f; F.fcy = (float)py + 0.5f;
         F.stk = &lds_stack[(tid >> 6) * STACK * 64 + (tid & 63)];
         F.giBounces = fr->giBounces;
+        F.frameIndex = u.frameIndex;
         const int SPP = max(u.spp, 1);
         const V3 camPos = ld3(u.camPos);
         const V3 dir = primaryDir(u, F.fcx, F.fcy);

@@ -87,28 +87,50 @@ RT_DEV void finish_pixel(const DevFrame *fr, const WaveBuf &wb, int slot, V3 fra
     wb.pendPos[slot] = pack_half4(gpos);
     wb.pendNrm[slot] = pack_half4(gnrm);
 }
+// History of the still-camera resolve inside a batch: frame k > 0 reads what frame k-1 of the same batch just produced, rounded to
+// fp16 as the RGBA16F target would hold it.
+struct ChainedHistory {
+    HistoryTex tex;
+    bool chained;
+    V4 value;
+    RT_DEV V4 own() const { return chained ? value : tex.own(); }
+    RT_DEV V4 at(float u, float v) const { return tex.at(u, v); }   // reprojection: never inside a batch (static camera only)
+};
 __global__ __launch_bounds__(256) void k_resolve(const DevFrame *__restrict__ fr, Targets tg, WaveBuf wb) {
     const RtUniforms &u = fr->u;
     int px, py;
     if (!pixel_of_slot(fr->g, blockIdx.x, threadIdx.x, px, py)) return;
     const int slot = blockIdx.x * 256 + threadIdx.x;
-    float4 pc = wb.pendC[slot];
-    V3 curr = mk3(pc.x, pc.y, pc.z);
-    V2 motionOut = mk2(pc.w, wb.pendMy[slot]);
     float uvx = ((float)px + 0.5f) / (float)fr->g.W, uvy = ((float)py + 0.5f) / (float)fr->g.H;   // rt_fullscreen.vert:44
-    V2 taaMotion = (u.cameraMoved == 1) ? motionOut : mk2(0.0f, 0.0f);
-    HistoryTex hist;
-    hist.prev = tg.prev; hist.prevAll = tg.prevAll; hist.blockSlots = tg.blockSlots; hist.g = &fr->g; hist.slot = slot;
-    V4 taa = resolveTAA(u, curr, uvx, uvy, taaMotion, u.frameIndex, hist);
-    tg.color[slot] = pack_half4(taa);
+    ChainedHistory hist;
+    hist.tex.prev = tg.prev; hist.tex.prevAll = tg.prevAll; hist.tex.blockSlots = tg.blockSlots; hist.tex.g = &fr->g; hist.tex.slot = slot;
+    hist.chained = false;
+    const int K = max(fr->g.batch, 1);
+    const int perFrame = fr->g.nLocalTiles * 256;   // slots of one frame of the batch
+    uint2 colorBits = make_uint2(0u, 0u);
+    V2 motionOut = mk2(0.0f, 0.0f);
+    int sk = slot;
+    for (int k = 0; k < K; ++k, sk += perFrame) {
+        float4 pc = wb.pendC[sk];
+        V3 curr = mk3(pc.x, pc.y, pc.z);
+        motionOut = mk2(pc.w, wb.pendMy[sk]);
+        V2 taaMotion = (u.cameraMoved == 1) ? motionOut : mk2(0.0f, 0.0f);
+        V4 taa = resolveTAA(u, curr, uvx, uvy, taaMotion, u.frameIndex + k, hist);
+        colorBits = pack_half4(taa);
+        hist.chained = true;
+        hist.value = unpack_half4(colorBits);        // what the next frame's texture(uPrevAccum, uv) returns: the fp16 target
+    }
+    sk -= perFrame;                                  // the targets hold the batch's last frame
+    tg.color[slot] = colorBits;
     tg.motion[slot] = pack_half2(motionOut);
-    tg.gpos[slot] = wb.pendPos[slot];
-    tg.gnrm[slot] = wb.pendNrm[slot];
+    tg.gpos[slot] = wb.pendPos[sk];
+    tg.gnrm[slot] = wb.pendNrm[sk];
 }
 RT_DEV void finish_miss(const DevFrame *fr, const WaveBuf &wb, int slot, int px, int py, V3 dir) {
     const RtUniforms &u = fr->u;
     Frag F;
     F.u = &u; F.sc = &fr->sc; F.fcx = (float)px + 0.5f; F.fcy = (float)py + 0.5f;
+    F.frameIndex = u.frameIndex + sub_frame_of_slot(fr->g, (uint32_t)slot);
     Work w;
     V3 r = sky<false>(F, dir, w);
     V3 frameSum = mk3(0.0f);
@@ -118,6 +140,8 @@ RT_DEV void finish_miss(const DevFrame *fr, const WaveBuf &wb, int slot, int px,
     finish_pixel(fr, wb, slot, frameSum, motionOut, mk4(0, 0, 0, 0), mk4(0, 0, 0, 0));
 }
 RT_DEV void slot_to_pixel(const FrameGeom &g, uint32_t slot, int &px, int &py) { pixel_of_slot(g, (int)(slot >> 8), (int)(slot & 255u), px, py); }
+// primary ray of pixel (px, py) in the batch's k-th frame: that frame's jitter (rt.frag:58-68)
+RT_DEV V3 primaryDirK(const DevFrame *fr, int k, int px, int py) { return primaryDirJ(fr->u, (float)px + 0.5f, (float)py + 0.5f, fr->jitterK[k][0], fr->jitterK[k][1]); }
 
 // wave-level append: returns this lane's index in the list (valid where pred)
 RT_DEV uint32_t wave_append(bool pred, uint32_t *counter) {
@@ -197,11 +221,11 @@ __global__ __launch_bounds__(256) void k_primary(const DevFrame *__restrict__ fr
     for (int k = 0; k < kAppendBatch; ++k) {
         const int tile = blockIdx.x * kAppendBatch + k;
         int px, py;
-        const bool live = tile < fr->g.nLocalTiles && pixel_of_slot(fr->g, tile, threadIdx.x, px, py);
+        const bool live = tile < fr->g.nLocalTiles * max(fr->g.batch, 1) && pixel_of_slot(fr->g, tile, threadIdx.x, px, py);
         const int slot = tile * 256 + threadIdx.x;
         bool cand = false;
         if (live) {
-            V3 dir = primaryDir(u, (float)px + 0.5f, (float)py + 0.5f);
+            V3 dir = primaryDirK(fr, sub_frame_of_tile(fr->g, tile), px, py);
             V3 rdInv = mk3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
             float tmin;
             cand = fr->sc.hasBVH && slab(ld3(u.camPos), rdInv, ld3(fr->sc.rootMin), ld3(fr->sc.rootMax), tmin) && !(tmin > u.inf);
@@ -235,7 +259,7 @@ struct PrimarySrc {   // ray i = primary ray of candidate i
         int px, py;
         slot_to_pixel(fr->g, p.slot, px, py);
         ro = ld3(fr->u.camPos);
-        rd = primaryDir(fr->u, (float)px + 0.5f, (float)py + 0.5f);
+        rd = primaryDirK(fr, sub_frame_of_slot(fr->g, p.slot), px, py);
     }
     RT_DEV void store_closest(uint32_t i, float t, int tri) const { outT[i] = t; outTri[i] = tri; }
     RT_DEV void store_any(uint32_t, bool) const {}
@@ -619,7 +643,7 @@ __global__ __launch_bounds__(256) void k_post_primary(const DevFrame *__restrict
                 const uint32_t slot = wb.cand[i];
                 int px, py;
                 slot_to_pixel(fr->g, slot, px, py);
-                finish_miss(fr, wb, (int)slot, px, py, primaryDir(fr->u, (float)px + 0.5f, (float)py + 0.5f));
+                finish_miss(fr, wb, (int)slot, px, py, primaryDirK(fr, sub_frame_of_slot(fr->g, slot), px, py));
             }
         }
         ap.note(k, hit);
@@ -729,7 +753,9 @@ RT_DEV HitCtx load_hit(const DevFrame *fr, const HitRec &h) {
     c.slot = h.slot;
     slot_to_pixel(fr->g, h.slot, c.px, c.py);
     c.F.u = &fr->u; c.F.sc = &fr->sc; c.F.fcx = (float)c.px + 0.5f; c.F.fcy = (float)c.py + 0.5f;
-    c.dir = primaryDir(fr->u, c.F.fcx, c.F.fcy);
+    const int k = sub_frame_of_slot(fr->g, h.slot);
+    c.F.frameIndex = fr->u.frameIndex + k;
+    c.dir = primaryDirK(fr, k, c.px, c.py);
     c.hp = ld3(fr->u.camPos) + c.dir * h.t;
     c.hn = tri_normal(fr->sc, h.tri);
     return c;
@@ -748,16 +774,16 @@ __global__ __launch_bounds__(256) void k_gen_direct(const DevFrame *__restrict__
     const uint32_t j = tid % live;
     HitCtx c = load_hit(fr, wb.hits[c0 + j]);
     const int SPP = max(u.spp, 1);
-    const int seed = (int)((uint32_t)u.frameIndex * (uint32_t)SPP + (uint32_t)s);
+    const int seed = (int)((uint32_t)c.F.frameIndex * (uint32_t)SPP + (uint32_t)s);
     GenDirectTracer tr;
     tr.wb = wb; tr.j = j; tr.s = s; tr.shadowMask = 0; tr.giCast = false;
     (void)directLightBVH(tr, c.F, SEG_DIRECT, c.hp, c.hn, seed, -c.dir);
     for (int k = 4; k < 6; ++k)   // sun / point rays are conditional (rt_lighting.glsl:123,194)
         if (!(tr.shadowMask & (1u << k))) wb.shT[(uint32_t)(wb.A + s * 6 + k) * wb.CH + j] = -1.0f;
     Work w;
-    if (u.enableGI == 1) (void)oneBounceGIBVH<GenDirectTracer, false>(tr, c.F, c.hp, c.hn, u.frameIndex, seed, w);
+    if (u.enableGI == 1) (void)oneBounceGIBVH<GenDirectTracer, false>(tr, c.F, c.hp, c.hn, c.F.frameIndex, seed, w);
     if (!tr.giCast) wb.giL[(uint32_t)s * wb.CH + j] = -1.0f;
-    if (s == 0 && wb.A > 0) (void)computeAO_BVH(tr, c.F, c.hp, c.hn, u.frameIndex);
+    if (s == 0 && wb.A > 0) (void)computeAO_BVH(tr, c.F, c.hp, c.hn, c.F.frameIndex);
 }
 
 // ---- stage: gen_gi -------------------------------------------------------------------------------
@@ -778,9 +804,9 @@ __global__ __launch_bounds__(256) void k_gen_gi(const DevFrame *__restrict__ fr,
     tr.wb = wb; tr.sc = &fr->sc; tr.inf = u.inf; tr.j = j; tr.s = s; tr.pos = pos; tr.shadowMask = 0;
     HitCtx c = load_hit(fr, wb.hits[c0 + j]);
     const int SPP = max(u.spp, 1);
-    const int seed = (int)((uint32_t)u.frameIndex * (uint32_t)SPP + (uint32_t)s);
+    const int seed = (int)((uint32_t)c.F.frameIndex * (uint32_t)SPP + (uint32_t)s);
     Work w;
-    (void)oneBounceGIBVH<GenGiTracer, false>(tr, c.F, c.hp, c.hn, u.frameIndex, seed, w);
+    (void)oneBounceGIBVH<GenGiTracer, false>(tr, c.F, c.hp, c.hn, c.F.frameIndex, seed, w);
     for (int k = 0; k < 6; ++k)
         if (!(tr.shadowMask & (1u << k))) wb.sh2T[(uint32_t)k * (wb.CH * (uint32_t)wb.SPP) + pos] = -1.0f;
 }
@@ -800,21 +826,21 @@ __global__ __launch_bounds__(256) void k_combine(const DevFrame *__restrict__ fr
     V2 motionOut = mk2(currNDC.x - prevNDC.x, currNDC.y - prevNDC.y);
     V3 nn = normalize(c.hn);
     float ao = 1.0f;
-    if (u.enableAO == 1) ao = computeAO_BVH(tr, c.F, c.hp, c.hn, u.frameIndex);
+    if (u.enableAO == 1) ao = computeAO_BVH(tr, c.F, c.hp, c.hn, c.F.frameIndex);
     V3 frameSum = mk3(0.0f);
     for (int s = 0; s < SPP; ++s) {
         tr.s = s;
-        int seed = (int)((uint32_t)u.frameIndex * (uint32_t)SPP + (uint32_t)s);
+        int seed = (int)((uint32_t)c.F.frameIndex * (uint32_t)SPP + (uint32_t)s);
         frameSum = frameSum + shadeSampleBVH<CombineTracer, false>(tr, c.F, c.hp, c.hn, -c.dir, seed, ao, w);
     }
     finish_pixel(fr, wb, (int)c.slot, frameSum, motionOut, mk4(c.hp.x, c.hp.y, c.hp.z, 1.0f), mk4(nn.x, nn.y, nn.z, 0.0f));
 }
 
-__global__ void k_accum_tally(const uint32_t *counts, unsigned long long *acc) {
+__global__ void k_accum_tally(const uint32_t *counts, unsigned long long *acc, int frames) {
     // acc: [0] candidates [1] hits [2] primary rays traced [3] shadow [4] bounce [5] bounce-shadow [6] frames
     int i = threadIdx.x;
     if (i < 6) acc[i] += counts[i];
-    if (i == 6) acc[6] += 1ull;
+    if (i == 6) acc[6] += (unsigned long long)frames;
 }
 
 template <class Src, bool ANY>
@@ -893,7 +919,8 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
                    unsigned long long *, bool count, int treeDepth, hipEvent_t evPrevDone) {
     if (count) { w->err = "work counters are produced by the megakernel pipeline (RT_PIPELINE_MEGAKERNEL)"; return RT_ERR_UNSUPPORTED; }
     const RtUniforms &u = host.u;
-    const size_t nSlots = (size_t)std::max(host.g.nLocalTiles, 1) * 256;
+    const int batch = std::max(host.g.batch, 1);
+    const size_t nSlots = (size_t)std::max(host.g.nLocalTiles, 1) * 256 * (size_t)batch;   // pixel slots of all frames of the batch
     const int SPP = std::max(u.spp, 1);
     const int A = (u.enableAO == 1) ? std::max(u.aoSamples, 0) : 0;
     const int S1 = A + 6 * SPP, S2 = 6 * SPP;
@@ -970,7 +997,8 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
     if (getenv("RT_TRACE_STATS") && !w->stats) { W_TRY(hipMalloc(&w->stats, 64 * sizeof(unsigned long long))); W_TRY(hipMemset(w->stats, 0, 64 * sizeof(unsigned long long))); }
     unsigned long long *S = w->stats;
     const TraceTune tune = w->tune;
-    const unsigned tiles = (unsigned)std::max(host.g.nLocalTiles, 0);
+    const unsigned tilesFrame = (unsigned)std::max(host.g.nLocalTiles, 0);
+    const unsigned tiles = tilesFrame * (unsigned)batch;
     if (tiles == 0) return RT_OK;
 
     rt_stage_begin(ctx, ST_PRIMARY, st);
@@ -1030,11 +1058,11 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
         hipLaunchKernelGGL(k_combine, dim3(gridH), dim3(256), 0, st, dFrame, tg, wb, c0);
         rt_stage_end(ctx, ST_COMBINE, 1, st);
     }
-    hipLaunchKernelGGL(k_accum_tally, dim3(1), dim3(64), 0, st, w->counts, w->acc);
+    hipLaunchKernelGGL(k_accum_tally, dim3(1), dim3(64), 0, st, w->counts, w->acc, batch);
     // temporal resolve: the one stage that needs the previous frame's COLOR0 (and must not overtake its target stores)
     if (evPrevDone) W_TRY(hipStreamWaitEvent(st, evPrevDone, 0));
     rt_stage_begin(ctx, ST_RESOLVE, st);
-    hipLaunchKernelGGL(k_resolve, dim3(tiles), dim3(256), 0, st, dFrame, tg, wb);
+    hipLaunchKernelGGL(k_resolve, dim3(tilesFrame), dim3(256), 0, st, dFrame, tg, wb);
     rt_stage_end(ctx, ST_RESOLVE, 1, st);
     W_TRY(hipGetLastError());
     return RT_OK;

@@ -38,9 +38,11 @@ class FrameGatherer:
     camera needs: reprojection reads the previous frame in other ranks' tiles.  Costs worldSize-1 more block copies per rank and
     frame over xGMI; leave it off for static cameras (a pixel then only reads its own history)."""
 
-    def __init__(self, renderer, which=RT_TARGET_COLOR, group=None, exchange_history=False):
+    def __init__(self, renderer, which=RT_TARGET_COLOR, group=None, exchange_history=False, gather_every=1):
         self.ren, self.which, self.group = renderer, which, group
         self.exchange_history = exchange_history
+        self.gather_every = max(1, int(gather_every))
+        self.frames = 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.device = torch.device("cuda", torch.cuda.current_device())
@@ -93,6 +95,16 @@ class FrameGatherer:
         if self.exchange_history and self.world > 1:
             self.ren.history_exchanged()       # the next frame's temporal resolve now waits for the all-gather too
         return self.frame
+
+    def after(self, n_frames=1, last=False):
+        """n_frames were rendered since the previous call (one rt_render_frames batch): gather the newest one if a gather_every boundary
+        was crossed, or if `last`.  -> whether a gather was enqueued."""
+        before = self.frames
+        self.frames += n_frames
+        if last or before // self.gather_every != self.frames // self.gather_every:
+            self.gather()
+            return True
+        return False
 
     def _local_of(self, which):
         ptr, nbytes = self.ren.local_target(which)
@@ -167,10 +179,16 @@ class NativeGatherer:
 
     def gather(self, force=False):
         """After render_frame: gather this frame if it is due (or force=True).  Asynchronous."""
-        self.frames += 1
+        return self.after(1, last=force)
+
+    def after(self, n_frames=1, last=False):
+        """n_frames were rendered since the previous call (one rt_render_frames batch): gather the newest one if a gather_every boundary
+        was crossed, or if `last`.  -> whether a gather was enqueued."""
+        before = self.frames
+        self.frames += n_frames
         if self.exchange_history and self.world > 1:
             self.ren.exchange_history()
-        if force or self.frames % self.gather_every == 0:
+        if last or before // self.gather_every != self.frames // self.gather_every:
             self.ren.gather_frame(self.which)
             return True
         return False

@@ -184,3 +184,68 @@ def test_reset_counters_with_frames_in_flight(orc):
         want = r.counters()
     assert got.to_dict() == want.to_dict()
     assert got.rays > W * H
+
+
+@pytest.mark.parametrize("world,rank", [(1, 0), (3, 1)])
+def test_batched_frames_equal_frame_by_frame(orc, world, rank):
+    """rt_render_frames: up to 16 consecutive frames of a static camera in one set of launches (virtual tiles per frame of the batch,
+    per-frame jitter and frame index, history chained through fp16 in the resolve kernel) == the same frames one by one, bit for
+    bit, for every batch length and in the middle of an accumulation; a moving frame or a change of any other uniform ends a batch."""
+    W, H = 200, 120
+    nodes, tris = scenes.bunny_bvh(4)
+    faces = scenes.tiny_env(16)
+    p = rt.default_render_params()
+    p.sppPerFrame = 2
+    cam = scenes.camera("closeup", aspect=W / H)
+    us = [rt.frame_uniforms(p, cam, W, H, f, True, nodes.shape[0], tris.shape[0]) for f in range(40)]
+    assert us[3].jitter[0] != us[4].jitter[0]              # the frames of a batch really differ in their jitter
+    with rt.Renderer(rank=rank, world_size=world) as one, rt.Renderer(rank=rank, world_size=world) as many:
+        for r in (one, many):
+            r.upload_bvh(nodes, tris)
+            r.upload_env(faces)
+            r.resize(W, H)
+        f = 0
+        for n in (1, 2, 3, 8, 5, 4, 11):                   # 11 = one batch of 8 + one of 3
+            for u in us[f:f + n]:
+                one.render_frame(u)
+            many.render_frames(us[f:f + n])
+            f += n
+            assert one.frame_index == many.frame_index == f
+            for a, b in zip(one.read_all(), many.read_all()):
+                assert np.array_equal(a, b), (n, f)
+        if world == 1:                                      # the last frame against the oracle as well (34 frames deep)
+            prev = None
+            for u in us[:f]:
+                want, _ = orc.render(u, nodes, tris, faces, prev)
+                prev = want[0]
+            for a, b in zip(many.read_all(), want):
+                assert np.array_equal(a, b)
+        tr = many.traced_rays()
+        assert tr.frames == f
+        # a different spp in the middle: the batch is cut there, the result is still the sequential one
+        p2 = rt.default_render_params()
+        p2.sppPerFrame = 3
+        mixed = [us[f], us[f + 1], rt.frame_uniforms(p2, cam, W, H, f + 2, True, nodes.shape[0], tris.shape[0]), us[f + 3]]
+        for u in mixed:
+            one.render_frame(u)
+        many.render_frames(mixed)
+        for a, b in zip(one.read_all(), many.read_all()):
+            assert np.array_equal(a, b)
+
+
+def test_batched_frames_fall_back_for_the_analytic_scene_and_the_megakernel(orc):
+    W, H = 96, 64
+    nodes, tris = scenes.bunny_bvh(3)
+    p = rt.default_render_params()
+    cam = scenes.camera("default", aspect=W / H)
+    for pipe, use_bvh in ((rt.RT_PIPELINE_AUTO, False), (rt.RT_PIPELINE_MEGAKERNEL, True)):
+        us = [rt.frame_uniforms(p, cam, W, H, f, use_bvh, nodes.shape[0], tris.shape[0]) for f in range(5)]
+        with rt.Renderer(pipeline=pipe) as a, rt.Renderer(pipeline=pipe) as b:
+            for r in (a, b):
+                r.upload_bvh(nodes, tris)
+                r.resize(W, H)
+            for u in us:
+                a.render_frame(u)
+            b.render_frames(us)
+            for x, y in zip(a.read_all(), b.read_all()):
+                assert np.array_equal(x, y)

@@ -16,6 +16,7 @@ ap.add_argument("--size", default="1920x1080")
 ap.add_argument("--scene", default="bunny")
 ap.add_argument("--world", type=int, default=1)
 ap.add_argument("--rank", type=int, default=0)
+ap.add_argument("--batch", type=int, default=1, help="frames per rt_render_frames call (bench.py's default is 8)")
 a = ap.parse_args()
 W, H = map(int, a.size.split("x"))
 import time
@@ -34,8 +35,9 @@ with rt.Renderer(pipeline=pipe, rank=a.rank, world_size=a.world) as r:
         r.render_frame(rt.frame_uniforms(p, cam, W, H, f, True, nodes.shape[0], tris.shape[0]))
     r.synchronize()
     r.enable_stage_timing(True)
-    for f in range(3, 3 + a.frames):
-        r.render_frame(rt.frame_uniforms(p, cam, W, H, f, True, nodes.shape[0], tris.shape[0]))
+    us = [rt.frame_uniforms(p, cam, W, H, f, True, nodes.shape[0], tris.shape[0]) for f in range(3, 3 + a.frames)]
+    for f in range(0, a.frames, max(a.batch, 1)):
+        r.render_frames(us[f:f + max(a.batch, 1)])
     r.synchronize()
     st = r.stage_times()
     d = {k: round(v["ms"] / a.frames, 3) for k, v in st["stages"].items()}
