@@ -191,6 +191,9 @@ int rt_render_ray(RtContext *ctx, const RtRenderParams *params, const RtCamera *
 typedef struct RtExtension { int32_t giBounces; int32_t reserved[3]; } RtExtension;
 int rt_set_extension(RtContext *ctx, const RtExtension *ext);   /* applies to the frames rendered after the call */
 
+/* `count` rt_render_ray calls with an unchanged camera and unchanged parameters, rendered through rt_render_frames (batched). */
+int rt_render_ray_frames(RtContext *ctx, const RtRenderParams *params, const RtCamera *cam, int useBVH, int showMotion, int count);
+
 int rt_synchronize(RtContext *ctx);
 
 /* Read one render target of the last frame into host memory: full width x height image, row 0 =

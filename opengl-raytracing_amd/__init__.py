@@ -175,6 +175,7 @@ SIGNATURES = {
     "rt_render_frames": (C.c_int, [C.c_void_p, C.POINTER(RtUniforms), C.c_int]),
     "rt_render_ray": (C.c_int, [C.c_void_p, C.POINTER(RtRenderParams), C.POINTER(RtCamera), C.c_int, C.c_int, _FP, _FP]),
     "rt_set_extension": (C.c_int, [C.c_void_p, C.POINTER(RtExtension)]),
+    "rt_render_ray_frames": (C.c_int, [C.c_void_p, C.POINTER(RtRenderParams), C.POINTER(RtCamera), C.c_int, C.c_int, C.c_int]),
     "rt_synchronize": (C.c_int, [C.c_void_p]),
     "rt_read_target": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "rt_write_target": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
@@ -517,6 +518,9 @@ class Renderer:
         """EXTENSION (not in the reference): bounces of the analytic / hybrid GI path."""
         e = RtExtension(giBounces=int(gi_bounces))
         self._check(lib().rt_set_extension(self._h, C.byref(e)))
+
+    def render_ray_frames(self, params, cam, count, use_bvh=False, show_motion=False):
+        self._check(lib().rt_render_ray_frames(self._h, C.byref(params), C.byref(cam), int(use_bvh), int(show_motion), int(count)))
 
     def synchronize(self):
         self._check(lib().rt_synchronize(self._h))

@@ -742,6 +742,33 @@ int rt_set_extension(RtContext *c, const RtExtension *ext) {
     return RT_OK;
 }
 
+// `count` consecutive rt_render_ray calls with the same camera and parameters, handed to rt_render_frames as one sequence (so an
+// accumulating static camera is rendered in batches).  Frame state (prev / curr view-projection) is kept exactly as rt_render_ray does.
+int rt_render_ray_frames(RtContext *c, const RtRenderParams *params, const RtCamera *cam, int useBVH, int showMotion, int count) {
+    if (!c || !params || !cam || count < 1) return RT_ERR_INVALID;
+    if (!c->sized) return fail(c, RT_ERR_STATE, "rt_render_ray_frames before rt_resize");
+    return guarded(c, "rt_render_ray_frames", [&]() -> int {
+        float V[16], P[16], VP[16];
+        rt_camera_view(cam, V);
+        rt_camera_proj(cam, P);
+        rt_mat4_mul(P, V, VP);
+        if (!c->haveFrameState) { std::memcpy(c->prevVP, VP, 64); c->haveFrameState = true; }
+        std::vector<RtUniforms> us((size_t)count);
+        float prev[16];
+        std::memcpy(prev, c->prevVP, 64);
+        for (int i = 0; i < count; ++i) {
+            const int moved = rt_camera_moved(VP, prev);
+            rt_make_uniforms(params, cam, V, VP, prev, c->g.W, c->g.H, c->frameIndex + i, moved, useBVH, showMotion, c->nNodes, c->nTris, c->dEnv != nullptr,
+                             &us[(size_t)i]);
+            std::memcpy(prev, VP, 64);
+        }
+        int rc = rt_render_frames(c, us.data(), count);
+        if (rc != RT_OK) return rc;
+        std::memcpy(c->prevVP, VP, 64);
+        return RT_OK;
+    });
+}
+
 int rt_synchronize(RtContext *c) {
     if (!c) return RT_ERR_INVALID;
     (void)hipSetDevice(c->cfg.device);

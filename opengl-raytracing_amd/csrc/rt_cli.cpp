@@ -291,20 +291,27 @@ int main(int argc, char **argv) {
     if (giBounces != 1) { RtExtension ext{}; ext.giBounces = giBounces; if ((rc = rt_set_extension(ctx, &ext)) != RT_OK) die(ctx, "rt_set_extension", rc); }
 
     const auto t0 = std::chrono::steady_clock::now();
-    for (int f = 0; f < frames; ++f) {
+    const bool lightMoving = params.pointLightOrbitEnabled != 0 && std::fabs(params.pointLightOrbitSpeed) > 1e-5f && params.pointLightOrbitRadius > 0.0f;
+    for (int f = 0; f < frames;) {
         // point-light orbit animation, application.cpp:341-348 (deg/s * s), with a fixed time step instead of glfwGetTime()
         if (params.pointLightOrbitEnabled) {
             params.pointLightYaw += params.pointLightOrbitSpeed * dt;
             if (params.pointLightYaw > 360.0f) params.pointLightYaw -= 360.0f;
             if (params.pointLightYaw < -360.0f) params.pointLightYaw += 360.0f;
         }
-        if ((rc = rt_render_ray(ctx, &params, &cam, useBVH, showMotion, nullptr, nullptr)) != RT_OK) die(ctx, "rt_render_ray", rc);
-        // an orbiting light is dynamic geometry for the accumulation: the history is invalid after every frame (application.cpp:538-553)
-        const bool lightMoving = params.pointLightOrbitEnabled != 0 && std::fabs(params.pointLightOrbitSpeed) > 1e-5f && params.pointLightOrbitRadius > 0.0f;
+        // a still scene accumulates: hand the library runs of frames (up to the next gather), it renders them in batches
+        int n = 1;
+        if (!lightMoving) {
+            n = frames - f;
+            if (ranks > 0) n = std::min(n, gatherEvery - f % gatherEvery);
+        }
+        if ((rc = rt_render_ray_frames(ctx, &params, &cam, useBVH, showMotion, n)) != RT_OK) die(ctx, "rt_render_ray_frames", rc);
+        f += n;
         // tile-parallel: COLOR0 to rank 0 every gatherEvery-th frame (what an interactive viewer would show) -- frames in between
         // need no exchange, the history a static camera reads is tile-local
-        if (ranks > 0 && ((f + 1) % gatherEvery == 0 || f + 1 == frames) && (rc = rt_gather_frame(ctx, RT_TARGET_COLOR)) != RT_OK) die(ctx, "rt_gather_frame", rc);
-        if (lightMoving && f + 1 < frames && (rc = rt_reset_accum(ctx)) != RT_OK) die(ctx, "rt_reset_accum", rc);
+        if (ranks > 0 && (f % gatherEvery == 0 || f == frames) && (rc = rt_gather_frame(ctx, RT_TARGET_COLOR)) != RT_OK) die(ctx, "rt_gather_frame", rc);
+        // an orbiting light is dynamic geometry for the accumulation: the history is invalid after every frame (application.cpp:538-553)
+        if (lightMoving && f < frames && (rc = rt_reset_accum(ctx)) != RT_OK) die(ctx, "rt_reset_accum", rc);
     }
     rt_synchronize(ctx);
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
