@@ -349,7 +349,7 @@ template <> struct StackOf<true> { typedef uint32_t type; };              // any
 
 template <class Src, bool ANY, int STACK, int LEAFB, bool STATS = false>
 __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, const float4 *__restrict__ wnodes, const float4 *__restrict__ tris, Src src,
-                                                uint32_t *head, uint32_t *tally, unsigned long long *gatherLoads, TraceTune tune,
+                                                uint32_t *head, unsigned long long *tally, unsigned long long *gatherLoads, TraceTune tune,
                                                 unsigned long long *stats = nullptr) {
     // STATS (diagnostic build only, RT_TRACE_STATS=1): [0] inner-node visits [1] leaf visits [2] triangle tests [3] inner-phase wave
     // iterations [4] active lanes summed over them [5] leaf-phase wave iterations [6] lanes with a leaf summed [7] refill rounds
@@ -619,7 +619,7 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
         }
     }
     if (tally) {
-        uint32_t s = traced;
+        unsigned long long s = traced;                     // 64-bit: a batch of 64-spp frames traces more than 2^32 rays per launch set
         for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
         if (lane == 0 && s) atomicAdd(tally, s);
     }
@@ -837,14 +837,15 @@ __global__ __launch_bounds__(256) void k_combine(const DevFrame *__restrict__ fr
 }
 
 __global__ void k_accum_tally(const uint32_t *counts, unsigned long long *acc, int frames) {
-    // acc: [0] candidates [1] hits [2] primary rays traced [3] shadow [4] bounce [5] bounce-shadow [6] frames
+    // acc: [0] candidates [1] hits [2] primary rays traced [3] shadow [4] bounce [5] bounce-shadow (the traversal kernels add to
+    // [2..5] themselves) [6] frames
     int i = threadIdx.x;
-    if (i < 6) acc[i] += counts[i];
+    if (i < 2) acc[i] += counts[i];
     if (i == 6) acc[6] += (unsigned long long)frames;
 }
 
 template <class Src, bool ANY>
-void launch_trace(hipStream_t st, int cus, int depth, const DevFrame *fr, const DevScene &hs, Src src, uint32_t *head, uint32_t *tally,
+void launch_trace(hipStream_t st, int cus, int depth, const DevFrame *fr, const DevScene &hs, Src src, uint32_t *head, unsigned long long *tally,
                   unsigned long long *gatherLoads, TraceTune tune, unsigned long long *stats = nullptr) {
     // Stack entries: closest-hit defers one sibling per binary level (8 B each); any-hit walks 4-wide nodes and can
     // defer three per two levels (4 B each).  Resident 256-thread blocks per CU follow from the LDS footprint.
@@ -1011,7 +1012,7 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
     TraceTune tuneP = tune;   // primary rays: one run = one 8x8 pixel block; their cost varies strongly across the screen, so short runs
     if (tuneP.chunk == 0) tuneP.chunk = 64;   // balance the tail (stage alone 0.50 / 0.62 / 0.86 ms with runs of 64 / 128 / 256)
     if (const char *e = getenv("RT_CHUNK_PRIMARY")) tuneP.chunk = atoi(e);
-    launch_trace<PrimarySrc, false>(st, traceBlocks, treeDepth, dFrame, host.sc, ps, &wb.heads[0], &wb.counts[2], w->acc + 8, tuneP, S ? S + 0 : nullptr);
+    launch_trace<PrimarySrc, false>(st, traceBlocks, treeDepth, dFrame, host.sc, ps, &wb.heads[0], w->acc + 2, w->acc + 8, tuneP, S ? S + 0 : nullptr);
     rt_stage_end(ctx, ST_TRACE_PRIMARY, 1, st);
 
     rt_stage_begin(ctx, ST_POST_PRIMARY, st);
@@ -1034,7 +1035,7 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
             qg.o = wb.giO; qg.d = wb.giD; qg.tm = wb.giL; qg.liveCount = &wb.counts[1]; qg.c0 = c0; qg.cap = wb.CH; qg.stride = wb.CH; qg.slots = (uint32_t)SPP;
             qg.outT = wb.giT; qg.outTri = wb.giTri; qg.outOcc = nullptr;
             rt_stage_begin(ctx, ST_TRACE_GI, st);
-            launch_trace<QueueSrc, false>(st, traceBlocks, treeDepth, dFrame, host.sc, qg, &wb.heads[(size_t)(1 + c * 3 + 1) * kHeadWords], &wb.counts[4], w->acc + 10, tune, S ? S + 32 : nullptr);
+            launch_trace<QueueSrc, false>(st, traceBlocks, treeDepth, dFrame, host.sc, qg, &wb.heads[(size_t)(1 + c * 3 + 1) * kHeadWords], w->acc + 4, w->acc + 10, tune, S ? S + 32 : nullptr);
             rt_stage_end(ctx, ST_TRACE_GI, 1, st);
 
             rt_stage_begin(ctx, ST_GEN_GI, st);
@@ -1047,11 +1048,11 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
             qq.b.stride = wb.CH * (uint32_t)SPP; qq.b.slots = 6u;
             qq.b.outT = nullptr; qq.b.outTri = nullptr; qq.b.outOcc = wb.occ2;
             rt_stage_begin(ctx, ST_TRACE_SHADOW, st);
-            launch_trace<DualQueueSrc, true>(st, traceBlocks, treeDepth, dFrame, host.sc, qq, &wb.heads[(size_t)(1 + c * 3 + 0) * kHeadWords], &wb.counts[3], w->acc + 9, tune, S ? S + 16 : nullptr);
+            launch_trace<DualQueueSrc, true>(st, traceBlocks, treeDepth, dFrame, host.sc, qq, &wb.heads[(size_t)(1 + c * 3 + 0) * kHeadWords], w->acc + 3, w->acc + 9, tune, S ? S + 16 : nullptr);
             rt_stage_end(ctx, ST_TRACE_SHADOW, 1, st);
         } else {
             rt_stage_begin(ctx, ST_TRACE_SHADOW, st);
-            launch_trace<QueueSrc, true>(st, traceBlocks, treeDepth, dFrame, host.sc, q1, &wb.heads[(size_t)(1 + c * 3 + 0) * kHeadWords], &wb.counts[3], w->acc + 9, tune, S ? S + 16 : nullptr);
+            launch_trace<QueueSrc, true>(st, traceBlocks, treeDepth, dFrame, host.sc, q1, &wb.heads[(size_t)(1 + c * 3 + 0) * kHeadWords], w->acc + 3, w->acc + 9, tune, S ? S + 16 : nullptr);
             rt_stage_end(ctx, ST_TRACE_SHADOW, 1, st);
         }
         rt_stage_begin(ctx, ST_COMBINE, st);
