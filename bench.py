@@ -78,6 +78,8 @@ def main():
     ap.add_argument("--no-default-camera", action="store_true")
     ap.add_argument("--batch", type=int, default=8, help="frames per rt_render_frames call: consecutive frames of the static camera share one set of "
                     "kernel launches (bit-identical to frame-by-frame rendering, tests/test_gpu_baseline_configs.py); 1 = one rt_render_frame per step")
+    ap.add_argument("--no-frame-by-frame", action="store_true", help="skip the unbatched comparison pass (config.ms_per_step_frame_by_frame); used under "
+                    "rocprofv3 so that the kernel statistics hold batched launches only")
     ap.add_argument("--gather-every", type=int, default=1, help="N > 1 GPUs: gather COLOR0 to rank 0 every k-th frame (1 = every frame; a static "
                     "camera's history is tile-local, so BASELINE configs[4] needs one gather per 32 accumulated frames)")
     ap.add_argument("--force-gather", action="store_true", help="rehearsal on one GPU: run the N > 1 code path (process group, communicator, "
@@ -259,6 +261,8 @@ def main():
             serial_stages = {k: v["ms"] / (2 * B1) for k, v in sst["stages"].items()}
             r1.close()
             # frame by frame (one rt_render_frame per step, three frames in flight), for comparison with the batched figure
+            if args.no_frame_by_frame:
+                raise StopIteration
             del os.environ["RT_LANES"]
             if old_lanes is not None:
                 os.environ["RT_LANES"] = old_lanes
@@ -274,9 +278,11 @@ def main():
             unbatched_ms = (time.perf_counter() - t2) / 40 * 1e3
             r2.close()
             os.environ["RT_LANES"] = "1"
+        except StopIteration:
+            pass
         finally:
             if old_lanes is None:
-                del os.environ["RT_LANES"]
+                os.environ.pop("RT_LANES", None)
             else:
                 os.environ["RT_LANES"] = old_lanes
     res = closeup

@@ -24,10 +24,13 @@ if has bench1m; then
 fi
 if has trace; then
   # kernel trace + stats of the bench command itself (frames overlapping on 3 lanes) and with one frame in flight
-  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 40 --warmup 5 --cpu-seconds 0 --no-default-camera > $OUT/trace.log 2>&1
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 40 --warmup 8 --cpu-seconds 0 --no-default-camera --no-frame-by-frame > $OUT/trace.log 2>&1
   cp $OUT/trace/*/*kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
-  RT_LANES=1 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace1 -- python3 $R/bench.py --steps 40 --warmup 5 --cpu-seconds 0 --no-default-camera > $OUT/trace1.log 2>&1
+  RT_LANES=1 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace1 -- python3 $R/bench.py --steps 40 --warmup 8 --cpu-seconds 0 --no-default-camera --no-frame-by-frame > $OUT/trace1.log 2>&1
   cp $OUT/trace1/*/*kernel_stats.csv $OUT/kernel_stats_one_frame_in_flight.csv 2>/dev/null
+  # frame by frame, one frame in flight: the launches the PMC passes below count (tools/prof_frames.py)
+  RT_LANES=1 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/tracepf -- python3 $R/tools/prof_frames.py --frames 4 > $OUT/tracepf.log 2>&1
+  cp $OUT/tracepf/*/*kernel_stats.csv $OUT/kernel_stats_frame_by_frame_one_in_flight.csv 2>/dev/null
   RT_LANES=1 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace1m -- python3 $R/tools/prof_frames.py --scene 1m --frames 4 > $OUT/trace1m.log 2>&1
   cp $OUT/trace1m/*/*kernel_stats.csv $OUT/kernel_stats_1m_one_frame_in_flight.csv 2>/dev/null
   echo "trace done"; ls $OUT/*.csv

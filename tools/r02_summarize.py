@@ -12,6 +12,7 @@ src = ROOT / "gpurun_out" / (sys.argv[1] if len(sys.argv) > 1 else "r02d")
 dst = ROOT / "profiles"
 commit = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
 copies = {"kernel_stats.csv": "r02_wavefront_kernel_stats.csv", "kernel_stats_one_frame_in_flight.csv": "r02_wavefront_kernel_stats_one_frame_in_flight.csv",
+          "kernel_stats_frame_by_frame_one_in_flight.csv": "r02_wavefront_kernel_stats_frame_by_frame_one_in_flight.csv",
           "kernel_stats_1m_one_frame_in_flight.csv": "r02_1m_kernel_stats_one_frame_in_flight.csv", "pmc_bunny_summary.txt": "r02_wavefront_pmc_summary.txt",
           "pmc_1m_summary.txt": "r02_1m_pmc_summary.txt", "gather_pmc.txt": "r02_gather_microbench_pmc.txt", "gather.txt": "r02_gather_microbench.txt",
           "bench.json": "r02_bench_line.json", "bench_1m.json": "r02_bench_line_1m.json"}
@@ -44,7 +45,7 @@ def stats(path):
 
 
 lines = []
-for tag, pm, ks, frames, tj in (("bunny (configs[1])", "pmc_bunny_summary.txt", "kernel_stats_one_frame_in_flight.csv", 7, "traffic_bunny.json"),
+for tag, pm, ks, frames, tj in (("bunny (configs[1]), frame by frame", "pmc_bunny_summary.txt", "kernel_stats_frame_by_frame_one_in_flight.csv", 7, "traffic_bunny.json"),
                                 ("1M triangles (configs[4] scene, 4 spp)", "pmc_1m_summary.txt", "kernel_stats_1m_one_frame_in_flight.csv", 5, "traffic_1m.json")):
     if not (src / pm).exists():
         continue
