@@ -294,7 +294,13 @@ def main():
     roofline = None
     st = res["stages"]
     if st and st["stages"]:
-        name, dom = max(st["stages"].items(), key=lambda kv: kv[1]["ms"])
+        # dominant = the stage with the largest device time when it has the GPU to itself (with several frames in flight the event spans
+        # of the timed region also contain time spent queueing behind other frames' kernels and can rank the stages differently)
+        if serial_stages:
+            name = max((k for k in serial_stages if k in st["stages"]), key=lambda k: serial_stages[k])
+            dom = st["stages"][name]
+        else:
+            name, dom = max(st["stages"].items(), key=lambda kv: kv[1]["ms"])
         launches = max(int(dom["launches"]), 1)
         avg_ms = dom["ms"] / launches
         overlapped_span_ms = None
