@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -1039,21 +1040,25 @@ struct RcclApi {
     std::string err;
     bool ok = false;
 };
+static void rccl_bind(RcclApi &a);
 RcclApi &rccl_api() {
     static RcclApi a;
-    if (a.ok || !a.err.empty()) return a;
+    static std::once_flag once;              // contexts on different threads may reach their first rt_comm_* call together
+    std::call_once(once, [] { rccl_bind(a); });
+    return a;
+}
+static void rccl_bind(RcclApi &a) {
     void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
     if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
     if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) { a.err = std::string("librccl.so.1 could not be loaded: ") + (dlerror() ? dlerror() : "?"); return a; }
-#define RT_BIND(field, name) do { a.field = (decltype(a.field))dlsym(h, #name); if (!a.field) { a.err = "librccl lacks " #name; return a; } } while (0)
+    if (!h) { const char *e = dlerror(); a.err = std::string("librccl.so.1 could not be loaded: ") + (e ? e : "?"); return; }
+#define RT_BIND(field, name) do { a.field = (decltype(a.field))dlsym(h, #name); if (!a.field) { a.err = "librccl lacks " #name; return; } } while (0)
     RT_BIND(getUniqueId, ncclGetUniqueId); RT_BIND(commInitRank, ncclCommInitRank); RT_BIND(commDestroy, ncclCommDestroy);
     RT_BIND(groupStart, ncclGroupStart); RT_BIND(groupEnd, ncclGroupEnd); RT_BIND(send, ncclSend); RT_BIND(recv, ncclRecv);
     RT_BIND(allGather, ncclAllGather); RT_BIND(errorString, ncclGetErrorString);
 #undef RT_BIND
     a.ok = true;
-    return a;
 }
 #define NCCL_TRY(c, expr)                                                                                           \
     do {                                                                                                            \

@@ -209,6 +209,7 @@ int main(int argc, char **argv) {
         world = ranks;
         if (!devices.empty() && (int)devices.size() != ranks) { std::fprintf(stderr, "rt_cli: --devices needs %d entries\n", ranks); return 2; }
         std::remove(idFile.c_str());
+        std::fflush(stdout); std::fflush(stderr);          // nothing buffered may be inherited by the children
         std::vector<pid_t> kids;
         bool child = false;
         for (int r = 0; r < ranks; ++r) {
