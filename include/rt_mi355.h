@@ -170,7 +170,9 @@ int rt_render_frame(RtContext *ctx, const RtUniforms *u);
 /* `count` consecutive frames (us[i] = the uniform block of frame rt_frame_index() + i) with as few launches as possible: runs of
  * frames that differ only in uJitter / uFrameIndex and have uCameraMoved == 0 -- an accumulating static camera, every BASELINE
  * configuration -- are rendered up to 16 at a time by one set of kernel launches (BVH scenes, wavefront pipeline); anything else
- * falls back to one rt_render_frame per frame.  Bit-identical to `count` calls of rt_render_frame; afterwards the four targets hold
+ * falls back to one rt_render_frame per frame.  In the reference this is `count` turns of Application::mainLoop with a standing camera
+ * (src/app/application.cpp:381-459: beginFrame, cameraMoved == false, the jitter of :398-405, renderRay, endFrame).
+ * Bit-identical to `count` calls of rt_render_frame; afterwards the four targets hold
  * the last frame.  This is what keeps a tile-parallel rank busy: with 1/8 of the pixels a single frame is too little work per launch. */
 int rt_render_frames(RtContext *ctx, const RtUniforms *us, int count);
 

@@ -202,3 +202,37 @@ def test_empty_and_single_triangle_bvh(orc):
                         assert np.array_equal(g, w_), (nodes.shape[0], pipeline, frame, name)
                     prev = want[0]
     assert cnt.hitPixels > 0          # the single triangle is in view
+
+
+@pytest.mark.parametrize("seed", range(CASES))
+def test_random_scene_batched_frames_equal_frame_by_frame_and_the_oracle(orc, seed):
+    """rt_render_frames on the random scenes (static camera): a random split of 9 frames into batches == the same frames one by one,
+    on one rank and on a random rank of a random world; the last frame of the single-rank run against the oracle too."""
+    nodes, tris, faces, p, cams, _, W, H = _case(seed)
+    rng = np.random.default_rng(9000 + seed)
+    cam = cams[0]
+    us = [rt.frame_uniforms(p, cam, W, H, f, True, nodes.shape[0], tris.shape[0], env_loaded=faces is not None) for f in range(9)]
+    cuts = sorted(set(int(x) for x in rng.integers(1, 9, size=int(rng.integers(0, 4)))))
+    parts = [us[a:b] for a, b in zip([0] + cuts, cuts + [9])]
+    world = int(rng.integers(1, 5))
+    for wsize, rank in ((1, 0), (world, int(rng.integers(0, world)))):
+        with rt.Renderer(rank=rank, world_size=wsize) as a, rt.Renderer(rank=rank, world_size=wsize) as b:
+            for r in (a, b):
+                r.upload_bvh(nodes, tris)
+                r.upload_env(faces)
+                r.resize(W, H)
+            for u in us:
+                a.render_frame(u)
+            for part in parts:
+                b.render_frames(part)
+            assert a.frame_index == b.frame_index == 9
+            ga, gb = a.read_all(), b.read_all()
+            for x, y in zip(ga, gb):
+                assert np.array_equal(x, y), (seed, wsize, rank, [len(q) for q in parts])
+            if wsize == 1:
+                prev = None
+                for u in us:
+                    want, _ = orc.render(u, nodes, tris, faces, prev)
+                    prev = want[0]
+                for x, y in zip(gb, want):
+                    assert np.array_equal(x, y), (seed, "oracle")
