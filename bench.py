@@ -1,53 +1,57 @@
 #!/usr/bin/env python3
 """bench.py -- Mray/s of the ray-trace hot path on MI355X (BASELINE.json metric).
 
-One "step" = one frame of the hot path (rt_render_frame through the C ABI) over the synthetic
+One "step" = one frame of the hot path (rt_render_frames through the C ABI) over the synthetic
 workload of BASELINE.json configs[1]: procedural bunny stand-in (81 920 triangles, median-split
 BVH), 1920x1080, 4 spp, one bounce (GI) + AO, Sky_01 environment, default RenderParams, static
 camera, frame indices continuing from the warm-up.  Inputs are resident in HBM before the timed
 region.  Headline camera = the close-up of SURVEY.md 8d (mesh ~45 % of the frame); the
 reference's default camera (mesh < 1 % of the frame) is reported beside it in "default_camera".
+`--obj a.obj [--obj b.obj]` renders a supplied mesh (e.g. the Stanford bunny the reference loads at
+src/app/application.cpp:260-272) through the same loader / default transform / builder instead.
 
-N > 1 (launched by torch.distributed.run, one process per GPU): the frame's 16x16 tiles are dealt
-round-robin to the ranks (the frame is fixed, so this is STRONG scaling), every rank holds a BVH
-replica, and each frame ends with one RCCL gather of COLOR0 to rank 0 over xGMI plus
-the un-tiling kernel.  value = rays of the whole frame / max-over-ranks time.
+N > 1: one process per GPU.  `python bench.py --gpus N` starts them itself (a torch.distributed.run
+child process, before anything here touches a GPU); under an outer torch.distributed.run the
+RANK / WORLD_SIZE environment is used as is.  The frame's 16x16 tiles are dealt round-robin to the
+ranks (the frame is fixed, so this is STRONG scaling), every rank holds a BVH replica, and each
+batch of frames ends with one RCCL gather of COLOR0 to rank 0 over xGMI plus the un-tiling
+kernel.  value = rays of the whole frame / max-over-ranks time.
 
 A "ray" is one traceBVH / traceBVHShadow call of the reference's shader for this frame
 (SURVEY.md 8d), counted by the library's work counters in a separate, untimed pass and checked
 against the oracle's count on the CPU sample.
+
+Self-check: the timed run submits frames in batches (rt_render_frames); afterwards the same frame
+indices are rendered again one rt_render_frame at a time and the COLOR0 targets of the last frame
+are compared (sha256).  A mismatch ends the run with a non-zero exit code.
 """
 import argparse
+import hashlib
 import json
 import os
+import signal
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
-
-import numpy as np
 
 ROOT = Path(__file__).resolve().parent
 for p in (str(ROOT), str(ROOT / "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-# Ceiling of the vector L1's gather path in G lane-loads/s (16 B per lane and load), per access shape, from tools/gather.hip with the
-# table L2-resident and 20 waves/CU (profiles/r02_gather_microbench_pmc.txt: the PMC passes show TCP_TOTAL_CACHE_ACCESSES = one per
-# divergent lane-load, processed at 0.8-1.0 per clock and CU): 64 lanes x 8 x dwordx4 from one 128-byte record per lane (the any-hit
-# kernel's 4-wide node) 1.05e9 loads in 1.502 ms; 64 lanes x 4 x dwordx4 from a 64-byte record (2-wide node) 5.24e8 in 0.888 ms.
-L1_GATHER_PEAK_G = {"trace_shadow": 1.05e9 / 1.502e-3 / 1e9, "trace_gi": 5.24e8 / 0.888e-3 / 1e9, "trace_primary": 5.24e8 / 0.888e-3 / 1e9}
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# The binding bound of the traversal kernels when the BVH is cache-resident: the vector L1 (TCP) retires at most ONE cache access per
+# clock and CU (tools/gather.hip under rocprofv3 --pmc, profiles/r02_gather_microbench_pmc.txt: 0.80-0.99 measured for divergent
+# 16-byte lane-loads of every record shape; lanes that read the same 16 bytes are merged into one access).
+CUS, PEAK_CLOCK_HZ = 256, 2.4e9
+L1_ACCESS_PEAK_G = CUS * PEAK_CLOCK_HZ / 1e9
 W, H, SPP = 1920, 1080, 4
-
-
-def algorithmic_bytes(c, npix):
-    """SURVEY.md 8d / BASELINE.md: reference-layout bytes of one frame."""
-    return 48 * c.nodeFetch + 48 * c.triFetch + npix * 36 + 12 * c.envLookup
 
 
 def kernel_source_sha():
     """sha256 over the device sources: ties a committed PMC traffic figure to the kernels it was measured on."""
-    import hashlib
     h = hashlib.sha256()
     for f in sorted((ROOT / "opengl-raytracing_amd" / "csrc").glob("*.h*")):
         h.update(f.name.encode())
@@ -67,58 +71,137 @@ def usable_cores():
     return n
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200, help="timed frames (default 200: a timed region of ~0.4 s)")
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--subdiv", type=int, default=6, help="icosphere subdivisions of the bunny stand-in (6 = 81 920 tris)")
+    ap.add_argument("--obj", action="append", default=[], help="render this .obj instead of the stand-in (repeat to merge several files into one "
+                    "triangle soup): rt_load_obj -> rt_gather_triangles_checked with the reference's default transform -> rt_build_bvh")
     ap.add_argument("--pipeline", default="auto", choices=["auto", "mega", "wave"])
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of EACH oracle (CPU baseline) sample -- one thread, then all cores; 0 = skip")
     ap.add_argument("--no-default-camera", action="store_true")
     ap.add_argument("--batch", type=int, default=8, help="frames per rt_render_frames call: consecutive frames of the static camera share one set of "
-                    "kernel launches (bit-identical to frame-by-frame rendering, tests/test_gpu_baseline_configs.py); 1 = one rt_render_frame per step")
-    ap.add_argument("--no-frame-by-frame", action="store_true", help="skip the unbatched comparison pass (config.ms_per_step_frame_by_frame); used under "
-                    "rocprofv3 so that the kernel statistics hold batched launches only")
-    ap.add_argument("--gather-every", type=int, default=1, help="N > 1 GPUs: gather COLOR0 to rank 0 every k-th frame (1 = every frame; a static "
+                    "kernel launches (bit-identical to frame-by-frame rendering: checked in every run, see config.batched_equals_frame_by_frame); "
+                    "1 = one rt_render_frame per step")
+    ap.add_argument("--no-frame-by-frame", action="store_true", help="skip the frame-by-frame pass (and with it the self-check); used under rocprofv3 so "
+                    "that the kernel statistics hold batched launches only")
+    ap.add_argument("--no-diagnostics", action="store_true", help="skip the one-launch-set-in-flight and merged-access passes (roofline block reduced)")
+    ap.add_argument("--gather-every", type=int, default=1, help="N > 1 GPUs: gather COLOR0 to rank 0 every k-th frame (1 = every batch; a static "
                     "camera's history is tile-local, so BASELINE configs[4] needs one gather per 32 accumulated frames)")
     ap.add_argument("--force-gather", action="store_true", help="rehearsal on one GPU: run the N > 1 code path (process group, communicator, "
-                    "gather per frame) with a world of one; launch with torch.distributed.run --nproc-per-node 1")
+                    "gather per batch) with a world of one (self-launched like N > 1 unless an outer launcher set WORLD_SIZE)")
     ap.add_argument("--gather", default="native", choices=["native", "torch"], help="N > 1: the library's own RCCL communicator (C ABI) or torch.distributed")
+    ap.add_argument("--launch", action="store_true", help="start the rank(s) through the self-launcher even for --gpus 1 (rehearsal of the N > 1 start-up "
+                    "on a one-GPU box, together with --force-gather)")
+    ap.add_argument("--dry-launch", action="store_true", help="--gpus N > 1 without WORLD_SIZE: print the child command / environment as JSON and exit")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="self-launched run: seconds before the launcher ends all ranks")
+    ap.add_argument("--rank-timeout", type=float, default=1200.0, help="N > 1: seconds after which a rank dumps its stacks and exits (watchdog)")
     # other BASELINE.json configurations, for side measurements (the default line is configs[1], the one `metric` is quoted on)
     ap.add_argument("--size", default="1920x1080", help="framebuffer WxH (configs[3]: 3840x2160)")
     ap.add_argument("--spp", type=int, default=4, help="samples per pixel and frame (configs[2-3]: 16, configs[4]: 64)")
     ap.add_argument("--scene", default="bunny", choices=["bunny", "1m"], help="1m = configs[4]'s 1M-triangle multi-object scene")
     ap.add_argument("--hybrid", action="store_true", help="EXTENSION (not in the reference; SURVEY 8d config 3 run B): the analytic scene "
-                    "(floor, glass / mirror / diffuse spheres) with the mesh added to it, reference default camera, megakernel")
+                    "(floor, glass / mirror / diffuse spheres) with the mesh added to it, reference default camera")
     ap.add_argument("--gi-bounces", type=int, default=1, help="EXTENSION: diffuse bounces of the analytic / hybrid GI path (configs[2]: 4)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_plan(args, argv):
+    """Child command + environment of a self-launched N-GPU run (nothing here has touched a GPU: torch is not even imported)."""
+    child_argv = [a for a in argv if a not in ("--dry-launch", "--launch")]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus, "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), str(ROOT / "bench.py")] + child_argv
+    env = {"HSA_ENABLE_IPC_MODE_LEGACY": "0", "OMP_NUM_THREADS": os.environ.get("OMP_NUM_THREADS", "4")}
+    return cmd, env
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` (N > 1) without a launcher: start one fresh process per GPU through torch.distributed.run as a CHILD
+    (never an exec: this process stays what it is), relay rank 0's JSON line, return non-zero if any rank failed or the run timed out."""
+    cmd, env = launch_plan(args, argv)
+    if args.dry_launch:
+        print(json.dumps({"cmd": cmd, "env": env, "ranks": args.gpus, "launch_timeout_s": args.launch_timeout}))
+        return 0
+    proc = subprocess.Popen(cmd, cwd=str(ROOT), env=dict(os.environ, **env), stdout=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        out, _ = proc.communicate(timeout=args.launch_timeout)
+    except subprocess.TimeoutExpired:
+        for sig in (signal.SIGTERM, signal.SIGKILL):          # the whole session: launcher + every rank
+            try:
+                os.killpg(proc.pid, sig)
+            except ProcessLookupError:
+                break
+            try:
+                proc.wait(timeout=15)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        sys.stderr.write("bench.py: the %d-rank run exceeded --launch-timeout %.0f s and was stopped\n" % (args.gpus, args.launch_timeout))
+        return 124
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    for ln in out.splitlines():
+        if not ln.startswith("{"):
+            sys.stderr.write(ln + "\n")
+    if proc.returncode != 0:
+        sys.stderr.write("bench.py: torch.distributed.run exited with %d\n" % proc.returncode)
+        return proc.returncode
+    if len(lines) != 1:
+        sys.stderr.write("bench.py: expected one JSON line from rank 0, got %d\n" % len(lines))
+        return 1
+    print(lines[0])
+    return 0
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.launch or args.force_gather):
+        raise SystemExit(self_launch(args, argv))
+    if args.dry_launch:
+        raise SystemExit("bench.py: --dry-launch needs --gpus N > 1 and no WORLD_SIZE in the environment")
     global W, H, SPP
     W, H = (int(v) for v in args.size.lower().split("x"))
     SPP = args.spp
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL between processes: before anything initialises HIP
+    import numpy as np
     import torch
     import torch.distributed as dist
     import opengl_raytracing_amd as rt
     from opengl_raytracing_amd.dist_gather import FrameGatherer, NativeGatherer
     import scenes
 
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL between processes: before anything initialises HIP
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
-        args.gpus = world
+    args.gpus = world
     torch.cuda.set_device(local_rank)
     multi = world > 1 or args.force_gather      # the tile-parallel code path (process group, communicator, gathers)
     if multi:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import faulthandler
+        faulthandler.dump_traceback_later(args.rank_timeout, exit=True)   # per-rank watchdog: a rank stuck in a collective ends itself
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     pipeline = {"auto": rt.RT_PIPELINE_AUTO, "mega": rt.RT_PIPELINE_MEGAKERNEL, "wave": rt.RT_PIPELINE_WAVEFRONT}[args.pipeline]
-    if args.scene == "1m":
+    mesh_desc = None
+    if args.obj:
+        # the reference's start-up: Model(path) -> gather_model_triangles(model, app.bvhTransform) -> build_bvh (src/scene/bvh.cpp:249-274),
+        # several files merged into one triangle soup first (multi-object scenes, BASELINE configs[4])
+        soups = []
+        for path in args.obj:
+            v_, f_ = rt.load_obj(path)
+            soups.append(rt.gather_triangles(v_, f_))
+        nodes, tris = rt.build_bvh(np.concatenate(soups, 0))
+        mesh_desc = "%s (%d tris, rt_load_obj -> default transform -> median-split BVH)" % (" + ".join(Path(p).name for p in args.obj), tris.shape[0])
+    elif args.scene == "1m":
         v, fidx = rt.meshgen.million_triangle_scene()
         nodes, tris = rt.build_bvh(rt.gather_triangles(v, fidx, np.eye(4, dtype=np.float32).reshape(-1)))
     else:
@@ -127,14 +210,15 @@ def main():
     params = rt.default_render_params()
     params.sppPerFrame = SPP
     npix = W * H
+    B = max(1, min(args.batch, 16))
 
     gather_path = {"path": "library-owned RCCL communicator (rt_comm_init / rt_gather_frame)", "gather_every": args.gather_every,
                    "when": "after each batch of frames (its last frame), and after the last timed frame"}
 
-    def make_renderer(count):
+    def make_renderer(count, pipe=None):
         # work counters (reference units) come from the reference-shaped megakernel; the timed run uses `pipeline`
         r = rt.Renderer(device=local_rank, rank=rank, world_size=world,
-                        pipeline=rt.RT_PIPELINE_MEGAKERNEL if count else pipeline, count_work=count)
+                        pipeline=rt.RT_PIPELINE_MEGAKERNEL if count else (pipeline if pipe is None else pipe), count_work=count)
         r.upload_bvh(nodes, tris)
         r.upload_env(faces)
         r.resize(W, H)
@@ -145,8 +229,12 @@ def main():
     def uniforms(cam, frame):
         return rt.frame_uniforms(params, cam, W, H, frame, rt.RT_SCENE_HYBRID if args.hybrid else True, nodes.shape[0], tris.shape[0])
 
-    def run_camera(cam, steps, warmup, timed_stage=True):
-        """-> dict(ms_per_step, counters summed over the timed frames (this rank), stage times)"""
+    def color_hash(ren):
+        """sha256 of this rank's COLOR0 target (RGBA16F bit patterns, row-major; pixels of other ranks' tiles read as zero)."""
+        return hashlib.sha256(np.ascontiguousarray(ren.read_target(rt.RT_TARGET_COLOR)).tobytes()).hexdigest()
+
+    def run_camera(cam, steps, warmup, timed_stage=True, check=False):
+        """-> dict(seconds, counters summed over the timed frames, stage times, ...)"""
         # untimed counting pass over the same frame indices (work counters slow the kernels down)
         rc = make_renderer(True)
         for f in range(warmup):
@@ -176,7 +264,6 @@ def main():
                 gather_path["path"] = "torch.distributed (RCCL) on the library's device pointers"
         # setup, not a step: every frame lane (3-4 streams with their own ray-queue arenas) allocates on its first frame; do that
         # before the W warm-up steps so that a small W cannot push a multi-GB hipMalloc into the timed region
-        B = max(1, min(args.batch, 16))
         setup_u = [uniforms(cam, f) for f in range(5 * B)]
         for b in range(5):
             ren.render_frames(setup_u[b * B:(b + 1) * B])
@@ -203,6 +290,7 @@ def main():
         run_steps(0, warmup)
         ren.synchronize()
         torch.cuda.synchronize()
+        ren.traced_rays(reset=True)
         if timed_stage:
             ren.enable_stage_timing(True)
         if multi:
@@ -218,20 +306,41 @@ def main():
         stages = ren.stage_times() if timed_stage else None
         traced = ren.traced_rays()
         info = ren.scene_info()
+        batched_hash = color_hash(ren) if check else None
         ren.close()
+
+        # Self-check + comparison figure: the same frame indices, one rt_render_frame per frame (three frames in flight).  Frames
+        # 0 .. warmup+steps-1 of a fresh accumulation, as above, so the last frame's COLOR0 must equal the batched run's bit for bit.
+        fbf_ms, fbf_hash = None, None
+        if check:
+            r2 = make_renderer(False)
+            for u2 in frames_u[:warmup]:
+                r2.render_frame(u2)
+            r2.synchronize()
+            t2 = time.perf_counter()
+            for u2 in frames_u[warmup:]:
+                r2.render_frame(u2)
+            r2.synchronize()
+            fbf_ms = (time.perf_counter() - t2) / max(steps, 1) * 1e3
+            fbf_hash = color_hash(r2)
+            r2.close()
+
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         cc = torch.tensor(list(cnt.to_dict().values()), dtype=torch.int64, device="cuda")
+        same = torch.tensor([1 if batched_hash == fbf_hash else 0], dtype=torch.int64, device="cuda")
         if multi:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dist.all_reduce(cc, op=dist.ReduceOp.SUM)
+            dist.all_reduce(same, op=dist.ReduceOp.MIN)
         total = rt.RtCounters(*[int(v) for v in cc.tolist()])
         tr = torch.tensor([traced.rays, traced.frames], dtype=torch.int64, device="cuda")
         if multi:
             dist.all_reduce(tr, op=dist.ReduceOp.SUM)
         frames_all = max(int(tr[1].item()) // world, 1)
-        traced_per_frame = int(tr[0].item()) * steps // frames_all // steps if traced.frames else 0
+        traced_per_frame = int(tr[0].item()) // frames_all if traced.frames else 0
         return {"seconds": float(tt.item()), "counters": total, "local_counters": cnt, "stages": stages,
-                "traced_per_frame": traced_per_frame, "traced": traced, "scene_info": info, "counted_frames": steps}
+                "traced_per_frame": traced_per_frame, "traced": traced, "scene_info": info, "counted_frames": steps,
+                "batched_hash": batched_hash, "fbf_hash": fbf_hash, "fbf_ms": fbf_ms, "same": bool(same.item()) if check else None}
 
     if args.hybrid:
         # the mesh stands among the analytic objects, seen from the reference's default camera (include/app/state.h:129-131)
@@ -239,175 +348,174 @@ def main():
         M[0, 3], M[1, 3], M[2, 3] = -0.1, 1.0, -0.5
         v_, f_ = rt.meshgen.bunny_standin(args.subdiv)
         nodes, tris = rt.build_bvh(rt.gather_triangles(v_, f_, M.T.reshape(-1)))
-    closeup = run_camera(scenes.camera("default" if args.hybrid else "closeup"), args.steps, args.warmup)
-    # serial stage breakdown (one frame in flight): in the timed run up to 3-4 frames overlap, which stretches every kernel's
-    # wall span; this untimed pass shows what each stage costs when it has the GPU to itself
-    serial_stages = None
-    unbatched_ms = None
-    if world == 1 and not args.hybrid:
-        old_lanes = os.environ.get("RT_LANES")
-        os.environ["RT_LANES"] = "1"
+    cam_kind = "default" if args.hybrid else "closeup"
+    check = not args.no_frame_by_frame
+    res = run_camera(scenes.camera(cam_kind), args.steps, args.warmup, check=check)
+
+    # ---- diagnostics, untimed, single GPU: (1) one launch set in flight (RT_LANES=1) in the SAME batched mode as the timed run: what each
+    # stage costs when it has the GPU to itself -- with 3-4 batches in flight an event span also contains the time a kernel shares the GPU
+    # with other batches' kernels; this pass gives the kernels' own durations, which is what rocprofv3's kernel trace reports
+    # (profiles/r03_*kernel_stats*.csv).  (2) the same with the instrumented traversal kernels (RT_TRACE_STATS=2): gather loads after merging the
+    # lanes of a wave that stand on the same record -- the unit the vector L1's one-access-per-clock ceiling applies to.
+    serial, merged = None, None
+    if world == 1 and not args.hybrid and not args.no_diagnostics:
+        saved = {k: os.environ.get(k) for k in ("RT_LANES", "RT_TRACE_STATS")}
+        cam1 = scenes.camera(cam_kind)
+        us1 = [uniforms(cam1, f) for f in range(4 * B)]
         try:
-            r1 = make_renderer(False)
-            cam1 = scenes.camera("closeup")
-            B1 = max(1, min(args.batch, 16))
-            us1 = [uniforms(cam1, f) for f in range(4 * B1)]
-            r1.render_frames(us1[:B1])
-            r1.render_frames(us1[B1:2 * B1])
-            r1.enable_stage_timing(True)
-            r1.render_frames(us1[2 * B1:3 * B1])
-            r1.render_frames(us1[3 * B1:])
-            sst = r1.stage_times()
-            serial_stages = {k: v["ms"] / (2 * B1) for k, v in sst["stages"].items()}
-            r1.close()
-            # frame by frame (one rt_render_frame per step, three frames in flight), for comparison with the batched figure
-            if args.no_frame_by_frame:
-                raise StopIteration
-            del os.environ["RT_LANES"]
-            if old_lanes is not None:
-                os.environ["RT_LANES"] = old_lanes
-            r2 = make_renderer(False)
-            us2 = [uniforms(cam1, f) for f in range(48)]
-            for u2 in us2[:8]:
-                r2.render_frame(u2)
-            r2.synchronize()
-            t2 = time.perf_counter()
-            for u2 in us2[8:]:
-                r2.render_frame(u2)
-            r2.synchronize()
-            unbatched_ms = (time.perf_counter() - t2) / 40 * 1e3
-            r2.close()
             os.environ["RT_LANES"] = "1"
-        except StopIteration:
-            pass
+            r1 = make_renderer(False)
+            r1.render_frames(us1[:B])
+            r1.render_frames(us1[B:2 * B])
+            r1.synchronize()
+            r1.traced_rays(reset=True)
+            r1.enable_stage_timing(True)
+            r1.render_frames(us1[2 * B:3 * B])
+            r1.render_frames(us1[3 * B:])
+            serial = {"stages": r1.stage_times()["stages"], "traced": r1.traced_rays(), "frames": 2 * B}
+            r1.close()
+            os.environ["RT_TRACE_STATS"] = "2"
+            r3 = make_renderer(False)
+            r3.render_frames(us1[:B])
+            r3.synchronize()
+            r3.traced_rays(reset=True)
+            r3.render_frames(us1[B:2 * B])
+            merged = r3.traced_rays()
+            r3.close()
         finally:
-            if old_lanes is None:
-                os.environ.pop("RT_LANES", None)
-            else:
-                os.environ["RT_LANES"] = old_lanes
-    res = closeup
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+
     rays = res["counters"].rays
     mray = rays / res["seconds"] / 1e6
     ms_per_step = res["seconds"] / args.steps * 1e3
 
-    # roofline of the dominant kernel (stage with the largest device time on this rank)
+    # ---- roofline of the dominant kernel
     roofline = None
     st = res["stages"]
     if st and st["stages"]:
-        # dominant = the stage with the largest device time when it has the GPU to itself (with several frames in flight the event spans
-        # of the timed region also contain time spent queueing behind other frames' kernels and can rank the stages differently)
-        if serial_stages:
-            name = max((k for k in serial_stages if k in st["stages"]), key=lambda k: serial_stages[k])
-            dom = st["stages"][name]
-        else:
-            name, dom = max(st["stages"].items(), key=lambda kv: kv[1]["ms"])
+        src = serial if serial else {"stages": st["stages"], "traced": res["traced"], "frames": args.steps}
+        name, dom = max(src["stages"].items(), key=lambda kv: kv[1]["ms"])
         launches = max(int(dom["launches"]), 1)
-        avg_ms = dom["ms"] / launches
-        overlapped_span_ms = None
-        if serial_stages and name in serial_stages:
-            # With several frames in flight the event span of a stage includes time its kernel shares the GPU with (or queues
-            # behind) other frames' kernels; the one-frame-in-flight pass gives the kernel's own duration, which is what
-            # rocprofv3's kernel trace reports (profiles/r02_*kernel_stats_one_frame_in_flight.csv).
-            overlapped_span_ms = avg_ms
-            avg_ms = serial_stages[name] * args.steps / launches
-        lc = res["local_counters"]
-        tr = res["traced"]
+        avg_ms = dom["ms"] / launches                  # HIP events around each launch of this kernel, on the stream it runs on
+        tr = src["traced"]
         info = res["scene_info"]
-        frames_tr = max(int(tr.frames), 1)
-        per_frame_launches = launches / args.steps
-        # (1) HBM roofline, the contract's: ALGORITHMIC bytes of this launch in THIS implementation's layout = what it has to
-        # move through HBM at least once: the ray records it reads (32-byte origin/direction + 4-byte tMax, 4 bytes of pixel
-        # slot for a primary ray), the results it writes (1 byte per any-hit ray, 8 per closest-hit ray) and the BVH arrays it
-        # walks, once (every re-read of a node is served by L1 / L2 / Infinity Cache or is waste).
+        # (1) HBM roofline, the contract's: ALGORITHMIC bytes of one launch in THIS implementation's layout = what it has to move through HBM
+        # at least once: the ray records it reads (32-byte origin/direction + 4-byte tMax; 4 bytes of pixel slot for a primary ray), the
+        # results it writes (1 byte per any-hit ray, 8 per closest-hit ray) and the BVH arrays it walks, once (every re-read of
+        # a node is served by L1 / L2 / Infinity Cache or is waste).
         rays_k = {"trace_primary": tr.primary, "trace_shadow": tr.shadow + tr.bounceShadow, "trace_gi": tr.bounce}
         rec_k = {"trace_primary": 4 + 8, "trace_shadow": 36 + 1, "trace_gi": 36 + 8}
         bvh_k = {"trace_primary": info.bytesNodes2 + info.bytesPairs, "trace_shadow": info.bytesNodes4 + info.bytesPairs,
                  "trace_gi": info.bytesNodes2 + info.bytesPairs}
         if name in rays_k:
-            rays_per_launch = rays_k[name] / frames_tr / per_frame_launches
+            rays_per_launch = rays_k[name] / launches
             bytes_per_launch = rays_per_launch * rec_k[name] + bvh_k[name]
-            attribution = ("%d B per ray traced (record in, result out) x %.0f rays + the BVH arrays this kernel walks once (%d B)"
+            attribution = ("%d B per ray traced (record in, result out) x %.0f rays per launch + the BVH arrays this kernel walks, once (%d B)"
                            % (rec_k[name], rays_per_launch, bvh_k[name]))
         else:
-            share = dom["ms"] / max(sum(v["ms"] for v in st["stages"].values()), 1e-9)
-            bytes_per_launch = (npix // world) * 36.0 * (1.0 if len(st["stages"]) == 1 else share) / per_frame_launches
-            attribution = "36 B per pixel (8 B history read + 28 B of target writes) x this kernel's share of the frame's device time"
+            frames_per_launch = src["frames"] / launches
+            bytes_per_launch = (npix // world) * 36.0 * frames_per_launch
+            attribution = "36 B per pixel (8 B history read + 28 B of target writes) x %.1f frames per launch" % frames_per_launch
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-        # the SURVEY 8d figure (REFERENCE layout: 48 B per nodeFetch / triFetch of the reference's loop for the rays this kernel
-        # traces) is kept beside it; it is not a traffic figure of this implementation (4.3x fewer rays are traversed, a node visit
-        # is one 64 / 112-byte record instead of 3 x 48 B) and exceeds the HBM peak on cache-resident scenes.
+        # the SURVEY 8d figure (REFERENCE layout: 48 B per nodeFetch / triFetch of the reference's loop for the rays this kernel traces) is kept
+        # beside it without a fraction: it is not a traffic figure of this implementation (4x fewer rays are traversed, a node visit is one
+        # 64 / 112-byte record instead of 3 x 48 B) and exceeds the HBM peak on cache-resident scenes.
+        lc = res["local_counters"]
         fetch_rest = lc.nodeFetch + lc.triFetch - lc.fetchPrimary - lc.fetchShadow - lc.fetchAO
         per_kind = {"trace_primary": lc.fetchPrimary, "trace_shadow": lc.fetchShadow + lc.fetchAO, "trace_gi": fetch_rest}
         ref_layout = None
         if name in per_kind:
-            ref_bytes = 48.0 * per_kind[name] / res["counted_frames"] / per_frame_launches
+            ref_bytes = 48.0 * per_kind[name] / res["counted_frames"] * (src["frames"] / launches)
             ref_layout = {"algorithmic_bytes_per_launch": ref_bytes, "bytes_per_s_GB": ref_bytes / (avg_ms * 1e-3) / 1e9, "frac": None,
                           "note": "SURVEY 8d units (48 B x the reference loop's nodeFetch + triFetch for these rays, megakernel counting pass); "
                                   "not bytes this implementation moves, so no fraction of a hardware peak is formed from it"}
-        # HBM bytes of that kernel per launch from the PMC passes of tools/collect_profiles.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-        # in separate passes, gfx950 2x fetch correction).  PMC cannot be collected inside this run: the figure is accepted only
-        # when the kernel sources it was measured on are the ones running now, else it is dropped.
+        # HBM bytes of that kernel per launch from the PMC passes of tools/r03_profile.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+        # passes over THIS command in its batched mode, gfx950 2x fetch correction).  PMC cannot be collected inside this run: the figure is
+        # accepted only when the kernel sources it was measured on are the ones running now, else it is dropped.
         traffic, traffic_src = None, None
-        kmap = {"trace_shadow": "DualQueueSrc, true", "trace_gi": "QueueSrc, false",
-                "trace_primary": "PrimarySrc", "primary": "k_primary", "combine": "k_combine", "gen_direct": "k_gen_direct"}
-        tj = ROOT / "profiles" / ("r02_traffic_%s.json" % ("1m" if args.scene == "1m" else "bunny"))
-        if world == 1 and tj.exists() and name in kmap and (W, H, SPP) == (1920, 1080, 4):
+        kmap = {"trace_shadow": "DualQueueSrc, true", "trace_gi": "QueueSrc, false", "trace_primary": "PrimarySrc"}
+        tj = ROOT / "profiles" / ("r03_traffic_%s.json" % ("1m" if args.scene == "1m" else "bunny"))
+        if world == 1 and tj.exists() and name in kmap and (W, H, SPP, B) == (1920, 1080, 4, 8) and not args.obj:
             tjd = json.load(open(tj))
             if tjd.get("kernel_source_sha256") == kernel_source_sha():
                 for k, v in tjd["kernels"].items():
-                    if kmap[name] in k:
-                        traffic = v["hbm_bytes_per_frame_corrected"] / per_frame_launches
+                    if kmap[name] in k and v.get("launches_with_rays"):
+                        traffic = v["hbm_bytes_corrected"] / v["launches_with_rays"]
                         traffic_src = {"kind": "profiled_offline", "file": str(tj.relative_to(ROOT)), "measured_at_commit": tjd.get("commit"),
-                                       "kernel_source_sha256": tjd.get("kernel_source_sha256")}
+                                       "kernel_source_sha256": tjd.get("kernel_source_sha256"), "mode": tjd.get("mode"),
+                                       "tcp_accesses_per_clk_per_cu_pmc": v.get("tcp_accesses_per_clk_per_cu")}
             else:
                 traffic_src = {"kind": "stale", "file": str(tj.relative_to(ROOT)),
                                "note": "kernel sources changed since the PMC passes; figure dropped"}
-        # (2) what binds these kernels when the BVH is cache-resident: the vector L1's gather path (tools/gather.hip +
-        # profiles/r02_gather_microbench_pmc.txt).  The traversal kernels count the 16-byte per-lane node / triangle loads they issue.
+        # (2) what binds these kernels when the BVH is cache-resident: the vector L1 retires at most one cache access per clock and CU.  The
+        # traversal kernels count the 16-byte per-lane node / triangle loads they issue; the instrumented pass counts them after merging the
+        # lanes of a wave that read the same record (one access).  frac = merged accesses / launch duration / (256 CUs x 2.4 GHz) <= 1.
         l1 = None
         gl = {"trace_primary": tr.gatherLoadsPrimary, "trace_shadow": tr.gatherLoadsShadow, "trace_gi": tr.gatherLoadsBounce}
-        if name in gl and tr.frames:
-            per_launch = gl[name] / frames_tr / per_frame_launches
-            rate = per_launch / (avg_ms * 1e-3) / 1e9
-            pk = L1_GATHER_PEAK_G[name]
-            l1 = {"unit": "G lane-loads/s (16 B each)", "lane_loads_per_launch": per_launch, "achieved": rate, "peak": pk,
-                  "frac": rate / pk, "bytes_per_s_TB": rate * 16 / 1e3,
-                  "peak_source": "tools/gather.hip, fully divergent lanes, this kernel's node record shape (profiles/r02_gather_microbench_pmc.txt: "
-                                 "~1 TCP cache access per clock and CU).  Lanes of a wave that read the same 16 bytes are merged by the L1, so the "
-                                 "kernel's own count over-states its TCP accesses by ~1.4x: profiles/README.md gives the PMC figure"}
+        if name in gl and merged is not None:
+            mg = {"trace_primary": (merged.mergedLoadsPrimary, merged.gatherLoadsPrimary), "trace_shadow": (merged.mergedLoadsShadow, merged.gatherLoadsShadow),
+                  "trace_gi": (merged.mergedLoadsBounce, merged.gatherLoadsBounce)}[name]
+            if mg[1] > 0 and mg[0] > 0:
+                factor = mg[0] / mg[1]
+                lane_loads = gl[name] / launches
+                acc = lane_loads * factor
+                rate = acc / (avg_ms * 1e-3) / 1e9
+                l1 = {"unit": "G L1 cache accesses/s (16 B each, lanes on the same record merged)", "lane_loads_per_launch": lane_loads,
+                      "merge_factor": factor, "accesses_per_launch": acc, "achieved": rate, "peak": L1_ACCESS_PEAK_G, "frac": rate / L1_ACCESS_PEAK_G,
+                      "peak_source": "one TCP cache access per clock and CU x 256 CUs x 2.4 GHz (profiles/r02_gather_microbench_pmc.txt: 0.80-0.99 measured "
+                                     "with divergent 16-byte lane-loads; lanes reading the same 16 bytes count once)",
+                      "merge_factor_source": "counted by the instrumented traversal kernels over one batch of this workload (distinct records per wave "
+                                             "step / lanes); the PMC figure of the same launches is in profiles/r03_derived.txt"}
         roofline = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                     "traffic_frac_of_peak": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                    "avg_launch_ms": avg_ms, "launches": launches, "algorithmic_bytes_per_launch": bytes_per_launch,
-                    "attribution": attribution,
+                    "avg_launch_ms": avg_ms, "launches": launches, "frames_per_launch": src["frames"] / launches,
+                    "algorithmic_bytes_per_launch": bytes_per_launch, "attribution": attribution,
                     "bvh_bytes": {"nodes_2wide": info.bytesNodes2, "nodes_4wide": info.bytesNodes4, "triangle_pairs": info.bytesPairs},
                     "cache_resident": bool(info.bytesNodes2 + info.bytesNodes4 + info.bytesPairs < 32 * 2**20),
                     "reference_layout": ref_layout, "l1_gather": l1,
-                    "avg_launch_ms_source": "HIP events, one frame in flight" if overlapped_span_ms is not None else "HIP events, timed region",
-                    "event_span_ms_with_frames_overlapping": overlapped_span_ms,
+                    "avg_launch_ms_source": ("HIP events around the launches of an untimed pass with ONE launch set in flight (RT_LANES=1), same batching as "
+                                             "the timed run; every launch traced rays" if serial else "HIP events, timed region (launch sets of several "
+                                             "batches overlap: spans include time shared with other kernels)"),
                     "note": "hbm frac = compulsory bytes of the launch / its duration / 8 TB/s.  With the BVH resident in L2 / Infinity Cache "
-                            "(cache_resident) HBM is not what bounds the kernel -- a low frac is expected; the binding bound is the L1 gather "
-                            "path (l1_gather), see DESIGN.md 4.3"}
+                            "(cache_resident) HBM is not what bounds the kernel -- a low frac is expected; the binding bound is the L1 access "
+                            "rate (l1_gather), see DESIGN.md 4.3"}
 
+    headline = (args.scene, W, H, SPP, args.hybrid, bool(args.obj)) == ("bunny", 1920, 1080, 4, False, False)
+    if args.obj:
+        mesh = mesh_desc
+    elif args.scene == "bunny":
+        mesh = "procedural bunny stand-in (icosphere subdiv %d, %d tris, median-split BVH)" % (args.subdiv, tris.shape[0])
+    else:
+        mesh = "1M-triangle multi-object scene (%d tris, median-split BVH)" % tris.shape[0]
+    if not args.hybrid:
+        workload = "%s%s, %dx%d, %d spp, GI 1 bounce + AO 4, Sky_01 env, close-up camera (-2,1.5,1.0)" % (
+            "configs[1]: " if headline else ("configs[1] with a supplied mesh: " if args.obj and (W, H, SPP) == (1920, 1080, 4) else "variant: "), mesh, W, H, SPP)
+    else:
+        workload = ("variant: %s inside the reference's analytic scene (floor, diffuse / glass / mirror spheres, light marker) -- EXTENSION mode=hybrid, "
+                    "not expressible in the reference -- %dx%d, %d spp, %d GI bounces + AO 4, Sky_01 env, reference default camera" % (mesh, W, H, SPP, args.gi_bounces))
     out = {
-        "metric": "Mray/s @1080p 4spp bunny BVH" if (args.scene, W, H, SPP, args.hybrid) == ("bunny", 1920, 1080, 4, False) else
+        "metric": "Mray/s @1080p 4spp bunny BVH" if (headline or (args.obj and (W, H, SPP, args.hybrid) == (1920, 1080, 4, False))) else
                   "Mray/s @%dx%d %dspp %s%s" % (W, H, SPP, args.scene, " + analytic scene, %d GI bounces (extension, not in the reference)" % args.gi_bounces if args.hybrid else " BVH"),
         "value": mray, "unit": "Mray/s", "value_traversed": res["traced_per_frame"] * args.steps / res["seconds"] / 1e6,
         "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": ("configs[1]: " if (args.scene, W, H, SPP, args.hybrid) == ("bunny", 1920, 1080, 4, False) else "variant: ")
-                               + ("procedural bunny stand-in (icosphere subdiv %d" % args.subdiv if args.scene == "bunny" else "1M-triangle multi-object scene (")
-                               + (", %d tris, median-split BVH), %dx%d, %d spp, GI 1 bounce + AO 4, Sky_01 env, close-up camera (-2,1.5,1.0)" % (tris.shape[0], W, H, SPP)
-                                  if not args.hybrid else
-                                  ", %d tris) inside the reference's analytic scene (floor, diffuse / glass / mirror spheres, light marker) -- EXTENSION mode=hybrid, "
-                                  "not expressible in the reference -- %dx%d, %d spp, %d GI bounces + AO 4, Sky_01 env, reference default camera, megakernel" % (tris.shape[0], W, H, SPP, args.gi_bounces)),
+        "dtype": "f32", "data": "synthetic" if not args.obj else "supplied .obj",
+        "config": {"workload": workload,
                    "pipeline": args.pipeline, "tiles": "16x16 round-robin over ranks" if world > 1 else "single GPU",
                    "gather": gather_path if multi else None,
-                   "frames_per_launch_set": max(1, min(args.batch, 16)),
+                   "frames_per_launch_set": B,
                    "batching": "rt_render_frames: consecutive frames of the static camera (they differ in uFrameIndex and uJitter only) share one set of "
-                               "kernel launches; every frame is fully rendered, results are bit-identical to one rt_render_frame per frame",
-                   "ms_per_step_frame_by_frame": unbatched_ms,
+                               "kernel launches; every frame is fully rendered",
+                   "batched_equals_frame_by_frame": res["same"],
+                   "color0_sha256": res["batched_hash"], "color0_sha256_frame_by_frame": res["fbf_hash"],
+                   "self_check": ("COLOR0 of frame %d (last timed frame) after the batched run == after one rt_render_frame per frame over the same frame "
+                                  "indices, sha256 of the RGBA16F bits%s" % (args.warmup + args.steps - 1, ", every rank its own tiles" if world > 1 else "")) if check else None,
+                   "ms_per_step_frame_by_frame": res["fbf_ms"],
                    "rays_per_frame": rays // args.steps, "msample_per_s": npix * SPP * args.steps / res["seconds"] / 1e6,
                    "hit_pixels": res["counters"].hitPixels // args.steps,
                    "rays_traversed_per_frame": res["traced_per_frame"],
@@ -418,9 +526,9 @@ def main():
     }
     if st:
         out["stage_ms_per_frame"] = {k: v["ms"] / args.steps for k, v in st["stages"].items()}
-        out["stage_ms_note"] = "HIP-event spans in the timed region; consecutive frames overlap on 3-4 streams, so spans add up to more than ms_per_step"
-    if serial_stages:
-        out["stage_ms_per_frame_one_frame_in_flight"] = serial_stages
+        out["stage_ms_note"] = "HIP-event spans in the timed region; consecutive batches overlap on 3-4 streams, so spans add up to more than ms_per_step"
+    if serial:
+        out["stage_ms_per_frame_one_launch_set_in_flight"] = {k: v["ms"] / serial["frames"] for k, v in serial["stages"].items()}
 
     if not args.no_default_camera and not args.hybrid:
         d = run_camera(scenes.camera("default"), args.steps, args.warmup, timed_stage=False)
@@ -432,7 +540,7 @@ def main():
         import tempfile
         import oracle as orc
         cores = usable_cores()
-        cam = scenes.camera("default" if args.hybrid else "closeup")
+        cam = scenes.camera(cam_kind)
         u = uniforms(cam, args.warmup)
         # the oracle's traversal + shade loop compiled -O3 -march=native on THIS host (bit-identical to the -O2 checker
         # build: tests/test_oracle_kat.py), (a) one thread -- the scalar figure the >= 10x target refers to -- (b) all usable cores.
@@ -464,10 +572,15 @@ def main():
                                "note": "the CPU traces every reference ray; the GPU pipeline skips duplicates (config.ray_accounting), so compare "
                                        "frame times (frame_seconds_estimate vs ms_per_step), or value_traversed, not the two Mray/s figures"}
     if multi:
+        import faulthandler
+        faulthandler.cancel_dump_traceback_later()
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
+    if check and res["same"] is False:
+        sys.stderr.write("bench.py: batched frames differ from frame-by-frame rendering (COLOR0 %s vs %s)\n" % (res["batched_hash"], res["fbf_hash"]))
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

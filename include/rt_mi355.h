@@ -284,10 +284,14 @@ int rt_get_scene_info(const RtContext *ctx, RtSceneInfo *out);
  * copies of a primary ray, the per-sample copies of the AO rays -- are traced once; disk-light shadow rays whose
  * weight is exactly zero are not traced at all).  RtCounters keeps counting in the reference's units.
  * gatherLoads*: 16-byte per-lane gather loads (BVH node and triangle records) the three traversal launches issued -- the unit of
- * the L1 gather roofline they run against (one divergent 16-byte lane-load per clock and CU, tools/gather.hip). */
+ * the L1 gather roofline they run against (one divergent 16-byte lane-load per clock and CU, tools/gather.hip).
+ * mergedLoads*: the same loads after merging the lanes of a wave that stand on the same record (they read the same 16-byte pieces,
+ * which the vector L1 serves as ONE cache access): what the one-access-per-clock ceiling applies to.  Counted only by the
+ * diagnostic traversal kernels (environment RT_TRACE_STATS=1 when the context renders); 0 otherwise. */
 typedef struct RtTracedRays {
     uint64_t candidatePixels, hitPixels, primary, shadow, bounce, bounceShadow, frames;
     uint64_t gatherLoadsPrimary, gatherLoadsShadow, gatherLoadsBounce;
+    uint64_t mergedLoadsPrimary, mergedLoadsShadow, mergedLoadsBounce;
 } RtTracedRays;
 int rt_get_traced_rays(RtContext *ctx, RtTracedRays *out, int reset);
 

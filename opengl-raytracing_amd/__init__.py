@@ -125,7 +125,8 @@ class RtStageTimes(_Struct):
 
 class RtTracedRays(_Struct):
     _fields_ = [(n, C.c_uint64) for n in ("candidatePixels", "hitPixels", "primary", "shadow", "bounce", "bounceShadow", "frames",
-                                             "gatherLoadsPrimary", "gatherLoadsShadow", "gatherLoadsBounce")]
+                                             "gatherLoadsPrimary", "gatherLoadsShadow", "gatherLoadsBounce",
+                                             "mergedLoadsPrimary", "mergedLoadsShadow", "mergedLoadsBounce")]
 
     @property
     def rays(self):

@@ -695,7 +695,15 @@ int rt_render_frame(RtContext *c, const RtUniforms *uIn) { return render_frames_
 int rt_render_frames(RtContext *c, const RtUniforms *us, int count) {
     if (!c || !us || count < 1) return RT_ERR_INVALID;
     if (!c->sized) return fail(c, RT_ERR_STATE, "rt_render_frames before rt_resize");
-    const bool wavefront = c->cfg.pipeline != RT_PIPELINE_MEGAKERNEL && c->cfg.countWork == 0 && us[0].useBVH == 1 && c->nNodes > 0 && us[0].nodeCount > 0 && us[0].triCount > 0;
+    // A run of frames shares one set of launches only if every frame of it would take the wavefront pipeline (decided per run from
+    // its first frame: the uniform blocks of a run agree in everything but jitter, so they agree in useBVH / nodeCount / triCount) and
+    // if the resolve of frame k > 0 is sure to take the still branch of resolveTAA (rt_taa.glsl:86-105), whose history is the pixel's
+    // own texel and is chained in registers.  With uTaaStillThresh <= 0 the test `length(motion) < thresh` fails even for zero motion
+    // and the reprojection branch would read the texture from BEFORE the batch: such frames go one by one.
+    auto batchable = [&](const RtUniforms &u) {
+        return c->cfg.pipeline != RT_PIPELINE_MEGAKERNEL && c->cfg.countWork == 0 && u.useBVH == 1 && c->nNodes > 0 && u.nodeCount > 0 && u.triCount > 0 &&
+               u.cameraMoved == 0 && (u.enableTAA == 0 || u.taaStillThresh > 0.0f);
+    };
     // uniform blocks of a batch must agree in everything but frameIndex (ignored anyway) and jitter
     auto same_but_jitter = [](const RtUniforms &a, const RtUniforms &b) {
         RtUniforms x = a, y = b;
@@ -706,8 +714,8 @@ int rt_render_frames(RtContext *c, const RtUniforms *us, int count) {
     int done = 0;
     while (done < count) {
         int k = 1;
-        if (wavefront && us[done].cameraMoved == 0)
-            while (k < RT_MAX_BATCH && done + k < count && us[done + k].cameraMoved == 0 && same_but_jitter(us[done], us[done + k])) ++k;
+        if (batchable(us[done]))
+            while (k < RT_MAX_BATCH && done + k < count && same_but_jitter(us[done], us[done + k])) ++k;
         float jit[RT_MAX_BATCH][2] = {};
         for (int q = 0; q < k; ++q) { jit[q][0] = us[done + q].jitter[0]; jit[q][1] = us[done + q].jitter[1]; }
         int rc = render_frames_impl(c, &us[done], k, jit);
@@ -763,10 +771,12 @@ int rt_render_ray_frames(RtContext *c, const RtRenderParams *params, const RtCam
                              &us[(size_t)i]);
             std::memcpy(prev, VP, 64);
         }
+        const int first = c->frameIndex;
         int rc = rt_render_frames(c, us.data(), count);
-        if (rc != RT_OK) return rc;
-        std::memcpy(c->prevVP, VP, 64);
-        return RT_OK;
+        // FrameState::endFrame (frame_state.h:81-84) runs after every rendered frame: if the sequence failed part-way, the frames
+        // that did render have advanced frameIndex and the camera state must follow them, exactly as with rt_render_ray per frame
+        if (rc == RT_OK || c->frameIndex != first) std::memcpy(c->prevVP, VP, 64);
+        return rc;
     });
 }
 
@@ -956,6 +966,7 @@ int rt_get_traced_rays(RtContext *c, RtTracedRays *out, int reset) {
     out->candidatePixels = v[0]; out->hitPixels = v[1]; out->primary = v[2]; out->shadow = v[3]; out->bounce = v[4];
     out->bounceShadow = v[5]; out->frames = v[6];
     out->gatherLoadsPrimary = v[8]; out->gatherLoadsShadow = v[9]; out->gatherLoadsBounce = v[10];
+    out->mergedLoadsPrimary = v[11]; out->mergedLoadsShadow = v[12]; out->mergedLoadsBounce = v[13];
     return RT_OK;
 }
 
@@ -1142,13 +1153,18 @@ int rt_gather_frame(RtContext *c, int which) {
         RcclApi &a = rccl_api();
         ncclComm_t comm = (ncclComm_t)c->comm;
         NCCL_TRY(c, a.groupStart());
+        // a failing send / recv must not leave the communicator inside an open group (later collectives and ncclCommDestroy would
+        // hang): close the group first, then report the first error
+        ncclResult_t r1 = ncclSuccess;
         if (root) {
-            for (int r = 1; r < c->g.world; ++r)
-                NCCL_TRY(c, a.recv((char *)c->dGathered[lane][which] + (size_t)r * block, block, ncclUint8, r, comm, st));
+            for (int r = 1; r < c->g.world && r1 == ncclSuccess; ++r)
+                r1 = a.recv((char *)c->dGathered[lane][which] + (size_t)r * block, block, ncclUint8, r, comm, st);
         } else {
-            NCCL_TRY(c, a.send(local, block, ncclUint8, 0, comm, st));
+            r1 = a.send(local, block, ncclUint8, 0, comm, st);
         }
-        NCCL_TRY(c, a.groupEnd());
+        const ncclResult_t r2 = a.groupEnd();
+        if (r1 != ncclSuccess) return fail(c, RT_ERR_HIP, "ncclSend/ncclRecv failed: %s", a.errorString(r1));
+        if (r2 != ncclSuccess) return fail(c, RT_ERR_HIP, "ncclGroupEnd failed: %s", a.errorString(r2));
     }
     if (root) {
         const size_t n = (size_t)c->g.W * c->g.H;

@@ -12,6 +12,7 @@
 // all call rt_comm_init, and every --gather-every k-th frame (and the last one) ends with rt_gather_frame -- for a static camera
 // the accumulation history is tile-local, so frames in between need no exchange at all.  Rank 0 presents from
 // the gathered targets and writes the same files a single-GPU run writes.
+#include <signal.h>
 #include <sys/wait.h>
 #include <unistd.h>
 
@@ -20,6 +21,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstddef>
+#include <cerrno>
 #include <algorithm>
 #include <cstring>
 #include <fstream>
@@ -123,6 +125,7 @@ int main(int argc, char **argv) {
     int W = 1920, H = 1080, frames = 1, device = 0, useBVH = 0, showMotion = 0;
     int giBounces = 1;
     int ranks = 0, gatherEvery = 1;          // ranks 0 = plain single-process run without a communicator
+    bool dryRun = false;                     // --dry-run: fork + id hand-over only, nothing touches a GPU (rehearsal of the launcher on any host)
     std::vector<int> devices;
     RtRenderParams params;
     rt_default_render_params(&params);
@@ -178,6 +181,7 @@ int main(int argc, char **argv) {
         else if (a == "--device") device = std::atoi(next());
         else if (a == "--ranks") ranks = std::atoi(next());
         else if (a == "--gather-every") gatherEvery = std::max(1, std::atoi(next()));
+        else if (a == "--dry-run") dryRun = true;
         else if (a == "--devices") { std::stringstream ss(next()); std::string t; while (std::getline(ss, t, ',')) devices.push_back(std::atoi(t.c_str())); }
         else if (a == "--bvh") useBVH = 1;
         else if (a == "--analytic") useBVH = 0;
@@ -196,7 +200,7 @@ int main(int argc, char **argv) {
         else { std::fprintf(stderr, "usage: rt_cli [--obj f.obj] [--env cross.png] [--size WxH] [--spp n] [--frames n] [--bvh|--analytic] [--motion]\n"
                                     "              [--cam x,y,z,yaw,pitch] [--fov deg] [--aspect a] [--exposure e] [--no-gi --no-ao --no-taa --no-svgf --no-env] [--out prefix]\n"
                                     "              [--hybrid [--gi-bounces n]]   EXTENSION: the analytic scene with the .obj mesh added to it, n diffuse GI bounces\n"
-                                    "              [--ranks N [--devices d0,d1,..] [--gather-every k]]   tile-parallel over N GPUs, one process each, RCCL gather to rank 0\n"
+                                    "              [--ranks N [--devices d0,d1,..] [--gather-every k] [--dry-run]]   tile-parallel over N GPUs, one process each, RCCL gather to rank 0\n"
                                     "              (--obj may be repeated; --dump-targets writes prefix_{color,motion,gpos,gnrm}.pfm; --scene file.json sets any of\n"
                                     "               the above and every RenderParams field by name)\n"); return a == "--help" ? 0 : 2; }
     }
@@ -204,25 +208,38 @@ int main(int argc, char **argv) {
 
     // ---- tile-parallel: one fresh process per GPU, forked before any GPU call (nothing above this line touches HIP)
     int rank = 0, world = 1;
-    const std::string idFile = out + ".rccl_id";
+    // the id file carries the launcher's pid: concurrent runs with the same --out never see each other's id
+    const std::string idFile = out + ".rccl_id." + std::to_string((long)getpid());
     if (ranks > 0) {
         world = ranks;
         if (!devices.empty() && (int)devices.size() != ranks) { std::fprintf(stderr, "rt_cli: --devices needs %d entries\n", ranks); return 2; }
         std::remove(idFile.c_str());
         std::fflush(stdout); std::fflush(stderr);          // nothing buffered may be inherited by the children
         std::vector<pid_t> kids;
-        bool child = false;
+        bool child = false, forkFailed = false;
         for (int r = 0; r < ranks; ++r) {
             pid_t pid = fork();
-            if (pid < 0) { std::perror("rt_cli: fork"); return 1; }
+            if (pid < 0) { std::perror("rt_cli: fork"); forkFailed = true; break; }
             if (pid == 0) { rank = r; child = true; break; }
             kids.push_back(pid);
         }
         if (!child) {
-            int bad = 0;
-            for (pid_t k : kids) { int st = 0; if (waitpid(k, &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) ++bad; }
+            // Wait for whichever rank ends first: a rank that dies before or inside rt_comm_init (bad --devices entry, rt_create or
+            // .obj failure on one rank) would leave the others in ncclCommInitRank / the grouped send-recv forever, so the first
+            // failure -- or a failed fork -- ends the remaining ranks.
+            int bad = forkFailed ? 1 : 0;
+            size_t left = kids.size();
+            auto stop_rest = [&]() { for (pid_t k : kids) if (k > 0) kill(k, SIGTERM); };
+            if (forkFailed) stop_rest();
+            while (left > 0) {
+                int st = 0;
+                const pid_t done = waitpid(-1, &st, 0);
+                if (done < 0) { if (errno == EINTR) continue; break; }
+                for (pid_t &k : kids) if (k == done) { k = -1; --left; }
+                if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) { if (!bad) stop_rest(); ++bad; }
+            }
             std::remove(idFile.c_str());
-            if (bad) std::fprintf(stderr, "rt_cli: %d of %d ranks failed\n", bad, ranks);
+            if (bad) std::fprintf(stderr, "rt_cli: %d of %d ranks failed or were stopped\n", bad, ranks);
             return bad ? 1 : 0;
         }
         device = devices.empty() ? rank : devices[(size_t)rank];
@@ -232,12 +249,17 @@ int main(int argc, char **argv) {
     RtDeviceConfig cfg{};
     cfg.device = device; cfg.rank = rank; cfg.worldSize = world; cfg.pipeline = RT_PIPELINE_AUTO;
     RtContext *ctx = nullptr;
-    int rc = rt_create(&cfg, &ctx);
-    if (rc != RT_OK) die(nullptr, "rt_create", rc);
+    int rc = RT_OK;
+    if (dryRun && ranks <= 0) { std::printf("[DRY] single process, device %d, no GPU call made\n", device); return 0; }
+    if (!dryRun) {
+        rc = rt_create(&cfg, &ctx);
+        if (rc != RT_OK) die(nullptr, "rt_create", rc);
+    }
     if (ranks > 0) {
         unsigned char id[RT_COMM_ID_BYTES];
         if (root) {
-            if ((rc = rt_comm_unique_id(id, sizeof id)) != RT_OK) die(nullptr, "rt_comm_unique_id", rc);
+            if (dryRun) { for (size_t q = 0; q < sizeof id; ++q) id[q] = (unsigned char)(q * 7u + 3u); }   // stand-in for ncclGetUniqueId
+            else if ((rc = rt_comm_unique_id(id, sizeof id)) != RT_OK) die(nullptr, "rt_comm_unique_id", rc);
             const std::string tmp = idFile + ".tmp";
             FILE *fp = std::fopen(tmp.c_str(), "wb");
             if (!fp || std::fwrite(id, 1, sizeof id, fp) != sizeof id) { std::fprintf(stderr, "rt_cli: cannot write %s\n", tmp.c_str()); return 1; }
@@ -251,6 +273,15 @@ int main(int argc, char **argv) {
                 if (!got) usleep(100 * 1000);
             }
             if (!got) { std::fprintf(stderr, "rt_cli: rank %d never saw %s\n", rank, idFile.c_str()); return 1; }
+        }
+        if (dryRun) {
+            bool ok = true;
+            for (size_t q = 0; q < sizeof id; ++q) ok = ok && id[q] == (unsigned char)(q * 7u + 3u);
+            std::printf("[DRY] rank %d of %d device %d id %s\n", rank, world, device, ok ? "ok" : "CORRUPT");
+            std::fflush(stdout);
+            if (const char *e = std::getenv("RT_CLI_DRY_FAIL_RANK")) if (std::atoi(e) == rank) return 3;   // test hook: one rank dies early
+            if (const char *e = std::getenv("RT_CLI_DRY_HANG_RANK")) if (std::atoi(e) == rank) for (;;) pause();   // test hook: a rank stuck in a collective
+            return ok ? 0 : 1;
         }
         if ((rc = rt_comm_init(ctx, id, sizeof id)) != RT_OK) die(ctx, "rt_comm_init", rc);
         if (root) std::printf("[RCCL] %d ranks, communicator up\n", world);
@@ -300,9 +331,10 @@ int main(int argc, char **argv) {
             if (params.pointLightYaw > 360.0f) params.pointLightYaw -= 360.0f;
             if (params.pointLightYaw < -360.0f) params.pointLightYaw += 360.0f;
         }
-        // a still scene accumulates: hand the library runs of frames (up to the next gather), it renders them in batches
+        // a still scene accumulates: hand the library runs of frames (up to the next gather), it renders them in batches.  The yaw
+        // above advances once per loop turn, so frames are only grouped when that changes nothing: orbit off, or a speed of exactly 0.
         int n = 1;
-        if (!lightMoving) {
+        if (!lightMoving && !(params.pointLightOrbitEnabled != 0 && params.pointLightOrbitSpeed != 0.0f)) {
             n = frames - f;
             if (ranks > 0) n = std::min(n, gatherEvery - f % gatherEvery);
         }

@@ -338,6 +338,18 @@ RT_DEV uint32_t nth_set(unsigned long long m, uint32_t n) {
     return pos;
 }
 
+// number of distinct keys among the lanes that call it together (diagnostic build only)
+RT_DEV uint32_t distinct_keys(uint32_t key) {
+    unsigned long long m = __ballot(1);
+    uint32_t n = 0;
+    while (m) {
+        const uint32_t k = (uint32_t)__shfl((int)key, __ffsll((long long)m) - 1, 64);
+        m &= ~__ballot(key == k);
+        n++;
+    }
+    return n;
+}
+
 // Tunables of the scheduler (overridable per context through RT_REFILL_MIN / RT_MIN_SEARCH for experiments).
 constexpr uint32_t kShards = 64, kShardStride = 32;   // cursor shards per trace launch, uint32 words between them (128 B)
 constexpr uint32_t kHeadWords = kShards * kShardStride;
@@ -353,7 +365,9 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
                                                 unsigned long long *stats = nullptr) {
     // STATS (diagnostic build only, RT_TRACE_STATS=1): [0] inner-node visits [1] leaf visits [2] triangle tests [3] inner-phase wave
     // iterations [4] active lanes summed over them [5] leaf-phase wave iterations [6] lanes with a leaf summed [7] refill rounds
-    unsigned long long st_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // [8] cycles in inner steps [9] in leaf phases [10] in refills [11] wave lifetime
+    unsigned long long st_[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // [8] cycles in inner steps [9] in leaf phases [10] in refills [11] wave lifetime
+    // [12] / [13] node / triangle gather loads after merging: lanes of a wave that stand on the same record read the same 16-byte pieces,
+    // which the vector L1 serves as one access (profiles/r02_gather_microbench_pmc.txt) -- distinct records per wave step x loads per record
     const unsigned long long tStart_ = STATS ? clock64() : 0ull;
     typedef typename StackOf<ANY>::type Entry;
     __shared__ Entry lds[4 * STACK * 64];
@@ -510,7 +524,7 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
             const unsigned long long tI_ = STATS ? clock64() : 0ull;
             if (STATS && lane == 0) { st_[3]++; st_[4] += (unsigned long long)__popcll(sm); }
             if (searching) {
-                if (STATS) st_[0]++;
+                if (STATS) { st_[0]++; const uint32_t dk = distinct_keys((uint32_t)ref); if (lane == (uint32_t)(__ffsll((long long)sm) - 1)) st_[12] += dk * (ANY ? 7u : 4u); }
                 gathers += ANY ? 7u : 4u;
                 if constexpr (ANY) {
                     // 4-wide node: up to four grandchild boxes per 128-byte record, order irrelevant for any-hit
@@ -580,6 +594,7 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
             for (int i = 0; i < count && !done; i += LEAFB) {
                 const float4 *t = sc.tris + (size_t)(first + (i >> 1)) * 5;
                 gathers += 5u * NP;
+                if (STATS) { const unsigned long long am = __ballot(1); const uint32_t dk = distinct_keys((uint32_t)(first + (i >> 1))); if (lane == (uint32_t)(__ffsll((long long)am) - 1)) st_[13] += dk * 5u * NP; }
                 float4 rec[NP][5];
 #pragma unroll
                 for (int k = 0; k < NP; ++k) { rec[k][0] = t[k * 5 + 0]; rec[k][1] = t[k * 5 + 1]; rec[k][2] = t[k * 5 + 2]; rec[k][3] = t[k * 5 + 3]; rec[k][4] = t[k * 5 + 4]; }
@@ -612,7 +627,7 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
     }
     if (STATS && lane == 0) st_[11] = clock64() - tStart_;
     if (STATS && stats) {
-        for (int q = 0; q < 12; ++q) {
+        for (int q = 0; q < 14; ++q) {
             unsigned long long v = st_[q];
             for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
             if (lane == 0 && v) atomicAdd(&stats[q], v);
@@ -883,6 +898,8 @@ struct RtWave {
     int launchCap = 0, chunkCap = 0;     // trace launches `heads` holds cursors for / chunks `counts` holds bounce counters for
     unsigned long long *acc = nullptr;   // traced-ray tallies accumulated over frames
     unsigned long long *stats = nullptr; // RT_TRACE_STATS=1: 4 stages x 8 diagnostic sums
+    uint32_t *hostHits = nullptr;        // pinned: the hit count of a batch that needs more than one chunk (read back once per batch)
+    bool chunksFromSlots = false;        // RT_CHUNKS_FROM_SLOTS=1 (tests): launch the chunk loop for every pixel slot, as rounds 1-2 did
 };
 
 RtWave *rt_wave_create(int cus) {
@@ -894,6 +911,7 @@ RtWave *rt_wave_create(int cus) {
     if (const char *e = getenv("RT_DEBUG_SKIP_TRAVERSAL")) w->tune.skipTraversal = atoi(e);
     if (const char *e = getenv("RT_LEAFB")) w->tune.leafb = atoi(e);
     if (const char *e = getenv("RT_MIN_SEARCH")) w->tune.minSearch = std::max(0, std::min(64, atoi(e)));
+    if (const char *e = getenv("RT_CHUNKS_FROM_SLOTS")) w->chunksFromSlots = atoi(e) != 0;
     return w;
 }
 void rt_wave_destroy(RtWave *w) {
@@ -904,6 +922,7 @@ void rt_wave_destroy(RtWave *w) {
     if (w->heads) (void)hipFree(w->heads);
     if (w->acc) (void)hipFree(w->acc);
     if (w->stats) (void)hipFree(w->stats);
+    if (w->hostHits) (void)hipHostFree(w->hostHits);
     delete w;
 }
 const char *rt_wave_error(const RtWave *w) { return w->err.c_str(); }
@@ -972,7 +991,7 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
         wb.shT = (float *)take(CH * (size_t)S1 * 4); wb.giL = (float *)take(CH * (size_t)SPP * 4); wb.sh2T = (float *)take(CH * (size_t)S2 * 4);
     }
     wb.CH = (uint32_t)CH; wb.A = A; wb.SPP = SPP;
-    const int nChunks = (int)((nSlots + CH - 1) / CH);
+    int nChunks = (int)((nSlots + CH - 1) / CH);   // upper bound (every pixel slot a hit); cut down to the hit count below
     // cursor table (one set of sharded cursors per trace launch) and per-chunk bounce counters: grown when a small queue budget
     // cuts the frame into more chunks than seen so far (4K / 16 spp at RT_QUEUE_BUDGET_MB=128 is 491 chunks).  Both arrays are
     // only touched by this lane's stream, which is drained first.
@@ -1019,6 +1038,19 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
     hipLaunchKernelGGL(k_post_primary, dim3((tiles + kAppendBatch - 1) / kAppendBatch), dim3(256), 0, st, dFrame, tg, wb);
     rt_stage_end(ctx, ST_POST_PRIMARY, 1, st);
 
+    // More than one chunk: the number of chunks that hold hits is known only on the device.  Launching the chunk loop for the upper
+    // bound (rounds 1-2) costs little time -- the kernels of an empty chunk return at once -- but fills the launch statistics with
+    // empty launches (bench.py's batches of eight 1080p frames: 5 launch sets, 2 of them with rays).  Such a batch is tens of
+    // milliseconds of work, so the hit count is read back once (this lane's stream only; the other lanes keep the GPU busy) and
+    // the hits are dealt over equal chunks.  A single-chunk frame -- every frame-by-frame BASELINE configuration -- never syncs.
+    if (nChunks > 1 && !w->chunksFromSlots) {
+        if (!w->hostHits) W_TRY(hipHostMalloc((void **)&w->hostHits, sizeof(uint32_t)));
+        W_TRY(hipMemcpyAsync(w->hostHits, &w->counts[1], sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        W_TRY(hipStreamSynchronize(st));
+        const size_t hits = *w->hostHits;
+        nChunks = (int)((hits + CH - 1) / CH);
+        if (nChunks > 0) { CH = align_up((hits + (size_t)nChunks - 1) / (size_t)nChunks, 256); wb.CH = (uint32_t)CH; }
+    }
     for (int c = 0; c < nChunks; ++c) {
         const uint32_t c0 = (uint32_t)((size_t)c * CH);
         const unsigned gridHS = (unsigned)((CH * (size_t)SPP + 255) / 256), gridH = (unsigned)((CH + 255) / 256);
@@ -1078,13 +1110,17 @@ int rt_wave_traced(RtWave *w, hipStream_t st, unsigned long long *out8, bool res
         unsigned long long v[64];
         W_TRY(hipMemcpy(v, w->stats, sizeof v, hipMemcpyDeviceToHost));
         static const char *nm[4] = {"primary", "shadow", "bounce", "bounce_shadow"};
+        const char *mode = getenv("RT_TRACE_STATS");
+        const bool quiet = mode && atoi(mode) >= 2;   // RT_TRACE_STATS=2: collect (rt_get_traced_rays' mergedLoads*), do not print
         for (int k = 0; k < 4; ++k) {
             const unsigned long long *q = v + k * 16;
             double rays = (double)std::max<unsigned long long>(out8[2 + k], 1);
-            fprintf(stderr, "[trace stats] %-13s rays %.3g | per ray: inner %.1f leaf %.1f tri %.1f | inner-phase lane util %.2f (%.3g wave-iters, %.0f cyc each) "
-                            "leaf-phase util %.2f (%.3g, %.0f cyc each) | refills %.3g (%.0f cyc each)\n",
+            if (!quiet) fprintf(stderr, "[trace stats] %-13s rays %.3g | per ray: inner %.1f leaf %.1f tri %.1f | inner-phase lane util %.2f (%.3g wave-iters, %.0f cyc each) "
+                            "leaf-phase util %.2f (%.3g, %.0f cyc each) | refills %.3g (%.0f cyc each) | gather loads per ray %.0f, after merging equal records %.0f\n",
                     nm[k], rays, q[0] / rays, q[1] / rays, q[2] / rays, q[3] ? q[4] / (64.0 * q[3]) : 0.0, (double)q[3], q[3] ? (double)q[8] / q[3] : 0.0,
-                    q[5] ? q[6] / (64.0 * q[5]) : 0.0, (double)q[5], q[5] ? (double)q[9] / q[5] : 0.0, (double)q[7], q[7] ? (double)q[10] / q[7] : 0.0);
+                    q[5] ? q[6] / (64.0 * q[5]) : 0.0, (double)q[5], q[5] ? (double)q[9] / q[5] : 0.0, (double)q[7], q[7] ? (double)q[10] / q[7] : 0.0,
+                    k < 3 ? out8[8 + k] / rays : 0.0, (q[12] + q[13]) / rays);
+            if (k < 3) out8[11 + k] = q[12] + q[13];   // k: 0 primary, 1 shadow (+ bounce-shadow: one launch), 2 bounce
         }
         if (reset) W_TRY(hipMemset(w->stats, 0, sizeof v));
     }

@@ -17,7 +17,8 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t stream, const rtd::Dev
 
 // tallies accumulated since the last reset, 16 words: [0] candidate pixels [1] hit pixels [2] primary [3] shadow+AO
 // [4] bounce [5] bounce-shadow rays actually traversed, [6] frames, [8..10] 16-byte gather loads issued by the primary /
-// any-hit / bounce traversal launches
+// any-hit / bounce traversal launches, [11..13] the same after merging the lanes of a wave that read the same record (only
+// counted by the diagnostic kernels, RT_TRACE_STATS=1; 0 otherwise)
 int rt_wave_traced(RtWave *w, hipStream_t stream, unsigned long long *out16, bool reset);
 
 // stage timing hooks (rt_api.hip); stage ids index rt_stage_name()

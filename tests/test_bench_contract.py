@@ -1,24 +1,32 @@
 """bench.py's output contract, on a small variant of the workload (the driver runs the default line itself): ONE JSON line with the
-metric keys, a physical roofline (0 < frac <= 1 against the HBM peak, the binding L1 figure beside it), the CPU baseline with one
-thread and all cores from the -O3 -march=native oracle build, and value / value_traversed consistent with ms_per_step."""
+metric keys, a physical roofline (0 < frac <= 1 against the HBM peak AND against the L1 access ceiling beside it), the launch duration
+from real launches, the batched-vs-frame-by-frame self-check, the CPU baseline with one thread and all cores from the -O3 -march=native
+oracle build, and value / value_traversed consistent with ms_per_step.  Also: a supplied .obj drives the same line (--obj), and the
+self-launcher brings up the tile-parallel code path (process group, RCCL communicator, gather) with a world of one."""
 import json
 import subprocess
 import sys
 
 import pytest
 
+import opengl_raytracing_amd as rt
 import scenes
 
 pytestmark = pytest.mark.gpu
 
+SMALL = ["--steps", "6", "--warmup", "2", "--size", "640x360", "--subdiv", "4"]
 
-def test_bench_line_contract():
-    cmd = [sys.executable, "bench.py", "--steps", "6", "--warmup", "2", "--size", "640x360", "--subdiv", "4", "--cpu-seconds", "0.5"]
-    out = subprocess.run(cmd, cwd=str(scenes.ROOT), capture_output=True, text=True, timeout=600)
+
+def _bench(args, timeout=600):
+    out = subprocess.run([sys.executable, "bench.py"] + args, cwd=str(scenes.ROOT), capture_output=True, text=True, timeout=timeout)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
-    d = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+def test_bench_line_contract():
+    d = _bench(SMALL + ["--cpu-seconds", "0.5"])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
               "config", "roofline", "cpu_baseline", "value_traversed"):
         assert k in d, k
@@ -27,14 +35,44 @@ def test_bench_line_contract():
     rays = d["config"]["rays_per_frame"]
     assert abs(d["value"] - rays / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 0.02
     assert 0 < d["value_traversed"] < d["value"]
+    # the timed mode (batches of frames) is checked against frame-by-frame rendering inside the run
+    c = d["config"]
+    assert c["batched_equals_frame_by_frame"] is True and c["color0_sha256"] == c["color0_sha256_frame_by_frame"] and len(c["color0_sha256"]) == 64
+    assert c["ms_per_step_frame_by_frame"] > 0
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert 0 < r["frac"] <= 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
-    assert r["algorithmic_bytes_per_launch"] > 0 and r["avg_launch_ms"] > 0
+    assert r["algorithmic_bytes_per_launch"] > 0 and r["avg_launch_ms"] > 0 and r["launches"] >= 1 and r["frames_per_launch"] >= 1
+    assert "ONE launch set in flight" in r["avg_launch_ms_source"]
     assert r["traffic"] is None or r["traffic_source"]["kind"] == "profiled_offline"
     assert r["reference_layout"] is None or r["reference_layout"]["frac"] is None
-    if r["l1_gather"]:
-        assert 0 < r["l1_gather"]["frac"] < 2
-    c = d["cpu_baseline"]
-    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["single_thread"]["cores"] == 1 and c["single_thread"]["value"] > 0
-    assert "-O3 -march=native" in c["sample"]
+    if r["kernel"].startswith("trace_"):
+        l1 = r["l1_gather"]
+        assert l1 is not None and 0 < l1["merge_factor"] <= 1 and 0 < l1["frac"] <= 1        # a ceiling that is exceeded is not a ceiling
+        assert abs(l1["frac"] - l1["achieved"] / l1["peak"]) < 1e-9 and l1["peak"] == 256 * 2.4
+    b = d["cpu_baseline"]
+    assert b["kind"] == "port" and b["cores"] >= 1 and b["value"] > 0 and b["single_thread"]["cores"] == 1 and b["single_thread"]["value"] > 0
+    assert "-O3 -march=native" in b["sample"]
+
+
+def test_bench_obj_line_equals_the_standin_line(tmp_path):
+    """bench.py --obj: the mesh written as .obj and read back by rt_load_obj gives the same frames (COLOR0 hash), rays and hit pixels as the
+    generated mesh -- a supplied Stanford bunny would drive the headline line the same way (application.cpp:260-272)."""
+    v, f = rt.meshgen.bunny_standin(4)
+    obj = tmp_path / "standin.obj"
+    rt.meshgen.write_obj(obj, v, f)
+    common = SMALL + ["--cpu-seconds", "0", "--no-default-camera", "--no-diagnostics"]
+    a = _bench(common)
+    b = _bench(common + ["--obj", str(obj)])
+    for k in ("rays_per_frame", "hit_pixels", "rays_traversed_per_frame", "color0_sha256"):
+        assert a["config"][k] == b["config"][k], k
+    assert "standin.obj (5120 tris" in b["config"]["workload"] and b["data"] == "supplied .obj"
+    assert b["config"]["batched_equals_frame_by_frame"] is True
+
+
+def test_bench_self_launch_rehearsal_world_of_one():
+    """--launch --force-gather: bench.py starts torch.distributed.run itself (as it does for --gpus N > 1), the rank brings up the process group
+    and the library's RCCL communicator and gathers after every batch."""
+    d = _bench(SMALL + ["--cpu-seconds", "0", "--no-default-camera", "--launch", "--force-gather", "--gpus", "1"])
+    assert d["n_gpus"] == 1 and d["config"]["gather"]["path"].startswith("library-owned RCCL")
+    assert d["config"]["batched_equals_frame_by_frame"] is True

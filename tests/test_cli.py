@@ -1,6 +1,8 @@
 """Headless C++ host (opengl-raytracing_amd/rt_cli, built from csrc/rt_cli.cpp): the reference's start-up + frame loop
 driven purely through the C ABI.  CPU: PNG writer round trip.  GPU: the CLI's PNG equals the frames the Python harness
 renders through the same library (and hence the oracle's, by the other parity tests)."""
+import glob
+import os
 import subprocess
 
 import numpy as np
@@ -32,6 +34,27 @@ def test_cli_is_built_and_prints_usage():
     assert CLI.exists(), "run __graft_entry__.build()"
     out = subprocess.run([str(CLI), "--help"], capture_output=True, text=True)
     assert out.returncode == 0 and "usage: rt_cli" in out.stderr
+
+
+def test_cli_ranks_launcher_dry_run(tmp_path):
+    """rt_cli --ranks N --dry-run (no GPU call anywhere): N children forked, rank r bound to --devices[r], the 128-byte id written by
+    rank 0 (atomically, into a file named after the launcher's pid) and read back intact by every other rank, the file removed."""
+    out = subprocess.run([str(CLI), "--ranks", "3", "--devices", "5,2,7", "--dry-run", "--out", str(tmp_path / "d")], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = sorted(ln for ln in out.stdout.splitlines() if ln.startswith("[DRY]"))
+    assert lines == ["[DRY] rank 0 of 3 device 5 id ok", "[DRY] rank 1 of 3 device 2 id ok", "[DRY] rank 2 of 3 device 7 id ok"]
+    assert not glob.glob(str(tmp_path / "d.rccl_id*"))
+    bad = subprocess.run([str(CLI), "--ranks", "2", "--devices", "0", "--dry-run"], capture_output=True, text=True, timeout=60)
+    assert bad.returncode == 2 and "--devices needs 2 entries" in bad.stderr
+
+
+def test_cli_ranks_launcher_stops_the_survivors_when_a_rank_dies(tmp_path):
+    """One rank exits non-zero while another sits in a (simulated) collective forever: the launcher ends the survivor and returns
+    non-zero instead of blocking in waitpid on the hung rank."""
+    env = dict(os.environ, RT_CLI_DRY_FAIL_RANK="1", RT_CLI_DRY_HANG_RANK="2")
+    out = subprocess.run([str(CLI), "--ranks", "3", "--dry-run", "--out", str(tmp_path / "d")], capture_output=True, text=True, timeout=60, env=env)
+    assert out.returncode == 1 and "ranks failed or were stopped" in out.stderr, out.stdout + out.stderr
+    assert not glob.glob(str(tmp_path / "d.rccl_id*"))
 
 
 @pytest.mark.gpu
@@ -185,4 +208,4 @@ def test_cli_ranks_mode_equals_the_single_process_run(tmp_path):
     assert "[RCCL] 1 ranks, communicator up" in b.stdout and "tile-parallel" in b.stdout
     for suffix in (".png", "_color.pfm", "_motion.pfm", "_gpos.pfm", "_gnrm.pfm"):
         assert (tmp_path / f"plain{suffix}").read_bytes() == (tmp_path / f"ranks{suffix}").read_bytes(), suffix
-    assert not (tmp_path / "ranks.rccl_id").exists()
+    assert not glob.glob(str(tmp_path / "ranks.rccl_id*"))

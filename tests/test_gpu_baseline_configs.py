@@ -249,3 +249,129 @@ def test_batched_frames_fall_back_for_the_analytic_scene_and_the_megakernel(orc)
             b.render_frames(us)
             for x, y in zip(a.read_all(), b.read_all()):
                 assert np.array_equal(x, y)
+
+
+def test_1080p_batches_of_eight_equal_frame_by_frame_and_the_oracle(orc):
+    """The mode bench.py times: 1920x1080, 4 spp, 81 920 triangles, rt_render_frames in batches of 8 -- 17 frames = two
+    full batches and a remainder of one, each batch cut into chunks by the ray-queue budget -- against one rt_render_frame per frame: all
+    four targets bit-equal after every batch; and a 64x32 window of the last frame (16 frames of history deep) against the oracle."""
+    W, H, FRAMES = 1920, 1080, 17
+    nodes, tris = scenes.bunny_bvh(6)
+    faces = scenes.env_faces("Sky_01")
+    p = rt.default_render_params()
+    p.sppPerFrame = 4
+    cam = scenes.camera("closeup")
+    us = [rt.frame_uniforms(p, cam, W, H, f, True, nodes.shape[0], tris.shape[0]) for f in range(FRAMES)]
+    with rt.Renderer() as one, rt.Renderer() as many:
+        for r in (one, many):
+            r.upload_bvh(nodes, tris)
+            r.upload_env(faces)
+            r.resize(W, H)
+        f = 0
+        for n in (8, 8, 1):
+            for u in us[f:f + n]:
+                one.render_frame(u)
+            many.render_frames(us[f:f + n])
+            f += n
+            for a, b in zip(one.read_all(), many.read_all()):
+                assert np.array_equal(a, b), f
+        got = many.read_all()
+        tr = many.traced_rays()
+        assert tr.frames == FRAMES and tr.hitPixels > FRAMES * W * H // 4
+    x0, y0, x1, y1 = 900, 500, 964, 532
+    prev = None
+    for u in us:
+        want, _ = orc.render(u, nodes, tris, faces, prev, region=(x0, y0, x1, y1), nthreads=16)
+        prev = want[0]
+    for g, w in zip(got, want):
+        assert np.array_equal(g[y0:y1, x0:x1], w[y0:y1, x0:x1])
+
+
+_BATCH_CHUNK_CODE = r'''
+import sys, numpy as np
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import opengl_raytracing_amd as rt, oracle as orc, scenes
+W, H, SPP, SUB = 256, 160, 2, 4
+nodes, tris = scenes.bunny_bvh(SUB); faces = scenes.tiny_env(16)
+p = rt.default_render_params(); p.sppPerFrame = SPP
+cam = scenes.camera("closeup", aspect=W / H)
+us = [rt.frame_uniforms(p, cam, W, H, f, True, nodes.shape[0], tris.shape[0]) for f in range(9)]
+with rt.Renderer(pipeline=rt.RT_PIPELINE_WAVEFRONT) as r:
+    r.upload_bvh(nodes, tris); r.upload_env(faces); r.resize(W, H)
+    r.render_frames(us[:5])          # one batch of five frames: ~90 k hits in 4096-hit chunks, chunk boundaries fall inside frames
+    r.render_frames(us[5:])          # and a batch of four
+    got = r.read_all()
+    hits = r.traced_rays().hitPixels
+assert hits > 9 * 4096 * 2, hits     # really many chunks per batch
+prev = None
+for u in us:
+    want, _ = orc.render(u, nodes, tris, faces, prev, nthreads=16)
+    prev = want[0]
+for g, w in zip(got, want):
+    assert np.array_equal(g, w)
+print("BATCH-CHUNKED-OK")
+'''
+
+
+@pytest.mark.parametrize("from_slots", [0, 1])
+def test_batched_frames_with_chunked_queues_against_the_oracle(from_slots):
+    """rt_render_frames x chunked ray queues (RT_QUEUE_BUDGET_MB=1: 4096-hit chunks), 256x160 at 2 spp, batches of 5 and 4 frames, against
+    the oracle 9 frames deep.  from_slots=1 launches the chunk loop for every pixel slot as rounds 1-2 did (RT_CHUNKS_FROM_SLOTS): more than
+    half of the launch sets of a batch are then empty trailing chunks; the default reads the hit count back and launches none."""
+    env = dict(os.environ, RT_QUEUE_BUDGET_MB="1", RT_CHUNKS_FROM_SLOTS=str(from_slots))
+    r = subprocess.run([sys.executable, "-c", _BATCH_CHUNK_CODE], cwd=str(scenes.ROOT), env=env, capture_output=True, text=True, timeout=900)
+    assert "BATCH-CHUNKED-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_mixed_sequences_fall_back_per_run(orc):
+    """ADVICE r02: rt_render_frames decides batching per run of frames, not once from the first frame -- [BVH, analytic, analytic, BVH, BVH]
+    renders (the analytic frames one by one on the megakernel) instead of failing with "a frame batch reached the megakernel" after frame 0."""
+    W, H = 96, 64
+    nodes, tris = scenes.bunny_bvh(3)
+    faces = scenes.tiny_env(8)
+    p = rt.default_render_params()
+    cam = scenes.camera("closeup", aspect=W / H)
+    kinds = [True, False, False, True, True, rt.RT_SCENE_HYBRID, rt.RT_SCENE_HYBRID, True]
+    us = [rt.frame_uniforms(p, cam, W, H, f, k, nodes.shape[0], tris.shape[0]) for f, k in enumerate(kinds)]
+    with rt.Renderer() as a, rt.Renderer() as b:
+        for r in (a, b):
+            r.upload_bvh(nodes, tris)
+            r.upload_env(faces)
+            r.resize(W, H)
+        for u in us:
+            a.render_frame(u)
+        b.render_frames(us)
+        assert a.frame_index == b.frame_index == len(us)
+        for x, y in zip(a.read_all(), b.read_all()):
+            assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("thresh", [0.0, -1.0])
+def test_batching_is_off_when_the_still_branch_cannot_be_taken(orc, thresh):
+    """ADVICE r02: with uTaaStillThresh <= 0 resolveTAA never takes the still branch (length(0,0) < 0 is false), so frame k of a batch would
+    reproject from the history texture of BEFORE the batch.  rt_render_frames renders such frames one by one; the result is the sequential
+    one and the oracle's."""
+    W, H = 120, 72
+    nodes, tris = scenes.bunny_bvh(3)
+    faces = scenes.tiny_env(8)
+    p = rt.default_render_params()
+    p.sppPerFrame = 2
+    p.taaStillThresh = thresh
+    cam = scenes.camera("closeup", aspect=W / H)
+    us = [rt.frame_uniforms(p, cam, W, H, f, True, nodes.shape[0], tris.shape[0]) for f in range(6)]
+    with rt.Renderer() as a, rt.Renderer() as b:
+        for r in (a, b):
+            r.upload_bvh(nodes, tris)
+            r.upload_env(faces)
+            r.resize(W, H)
+        for u in us:
+            a.render_frame(u)
+        b.render_frames(us)
+        for x, y in zip(a.read_all(), b.read_all()):
+            assert np.array_equal(x, y)
+        got = b.read_all()
+    prev = None
+    for u in us:
+        want, _ = orc.render(u, nodes, tris, faces, prev)
+        prev = want[0]
+    _assert_equal(got, want, orc, f"taaStillThresh={thresh}")
