@@ -31,6 +31,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -338,8 +339,12 @@ RT_DEV uint32_t nth_set(unsigned long long m, uint32_t n) {
     return pos;
 }
 
-// number of distinct keys among the lanes that call it together (diagnostic build only)
-RT_DEV uint32_t distinct_keys(uint32_t key) {
+// Diagnostic build only: how many cache accesses the lanes that call this together cost the vector L1 when each reads the record `key`.
+// The texture addresser takes a wave's 16-byte lane-loads four adjacent lanes at a time and merges lanes of such a quad that read
+// the same bytes (tools/gather.hip mode 6 under rocprofv3 --pmc: four adjacent lanes on one record = 0.25 accesses per lane-load);
+// lanes further apart are not merged (the kernels' PMC access counts are 2-3 x their wave-wide distinct-record counts).
+//   -> number of (quad, record) pairs = lanes whose key differs from every lower active lane of their quad.
+RT_DEV uint32_t wave_distinct(uint32_t key) {   // distinct keys among the calling lanes
     unsigned long long m = __ballot(1);
     uint32_t n = 0;
     while (m) {
@@ -348,6 +353,17 @@ RT_DEV uint32_t distinct_keys(uint32_t key) {
         n++;
     }
     return n;
+}
+RT_DEV uint32_t quad_distinct(uint32_t key) {
+    const unsigned long long am = __ballot(1);
+    const uint32_t lane = threadIdx.x & 63u, q0 = lane & ~3u;
+    bool first = true;
+#pragma unroll
+    for (uint32_t j = 0; j < 3; ++j) {
+        const uint32_t kj = (uint32_t)__shfl((int)key, (int)(q0 + j), 64);
+        if (j < (lane & 3u) && ((am >> (q0 + j)) & 1ull) && kj == key) first = false;
+    }
+    return (uint32_t)__popcll(__ballot(first));
 }
 
 // Tunables of the scheduler (overridable per context through RT_REFILL_MIN / RT_MIN_SEARCH for experiments).
@@ -359,19 +375,22 @@ struct TraceTune { int refillMin; int minSearch; int chunk; int leafb; int skipT
 template <bool ANY> struct StackOf { typedef StackEntry type; };          // closest: {deferred child, its entry distance}
 template <> struct StackOf<true> { typedef uint32_t type; };              // any-hit: the pop-time cull never fires (tMax is constant)
 
-template <class Src, bool ANY, int STACK, int LEAFB, bool STATS = false>
+// Per-lane traversal stacks live in dynamic LDS sized for THIS tree (stackEntries per lane): the resident workgroups per CU -- and
+// with them the memory-level parallelism of these latency-bound loops -- follow from the scene's depth instead of from a few
+// compiled-in sizes (1 M triangles, depth 18: 4 / 5 workgroups per CU for closest- / any-hit instead of 3 / 4 with 24- and 36-entry stacks).
+extern __shared__ __align__(16) unsigned char rt_dyn_lds[];
+template <class Src, bool ANY, int LEAFB, bool STATS = false>
 __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, const float4 *__restrict__ wnodes, const float4 *__restrict__ tris, Src src,
                                                 uint32_t *head, unsigned long long *tally, unsigned long long *gatherLoads, TraceTune tune,
-                                                unsigned long long *stats = nullptr) {
+                                                int stackEntries, unsigned long long *stats = nullptr) {
     // STATS (diagnostic build only, RT_TRACE_STATS=1): [0] inner-node visits [1] leaf visits [2] triangle tests [3] inner-phase wave
     // iterations [4] active lanes summed over them [5] leaf-phase wave iterations [6] lanes with a leaf summed [7] refill rounds
-    unsigned long long st_[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // [8] cycles in inner steps [9] in leaf phases [10] in refills [11] wave lifetime
-    // [12] / [13] node / triangle gather loads after merging: lanes of a wave that stand on the same record read the same 16-byte pieces,
-    // which the vector L1 serves as one access (profiles/r02_gather_microbench_pmc.txt) -- distinct records per wave step x loads per record
+    unsigned long long st_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // [14] / [15]: the same with wave-wide merging (distinct records per wave step)   // [8] cycles in inner steps [9] in leaf phases [10] in refills [11] wave lifetime
+    // [12] / [13] node / triangle gather loads after merging: adjacent lanes (a quad) that stand on the same record read the same 16-byte
+    // pieces, which the vector L1 serves as one access (quad_distinct above) -- (quad, record) pairs per wave step x loads per record
     const unsigned long long tStart_ = STATS ? clock64() : 0ull;
     typedef typename StackOf<ANY>::type Entry;
-    __shared__ Entry lds[4 * STACK * 64];
-    Entry *stk = &lds[(threadIdx.x >> 6) * STACK * 64 + (threadIdx.x & 63)];
+    Entry *stk = reinterpret_cast<Entry *>(rt_dyn_lds) + (threadIdx.x >> 6) * stackEntries * 64 + (threadIdx.x & 63);
     DevScene sc = fr->sc;   // private copy: scene constants stay in SGPRs instead of being re-read per step
     sc.tris = tris;         // kernel-argument copies: known-global pointers (global_load, not flat_load)
     const float4 *__restrict__ nodes = wnodes;   // 2-wide records for closest-hit, 4-wide records for any-hit
@@ -524,7 +543,7 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
             const unsigned long long tI_ = STATS ? clock64() : 0ull;
             if (STATS && lane == 0) { st_[3]++; st_[4] += (unsigned long long)__popcll(sm); }
             if (searching) {
-                if (STATS) { st_[0]++; const uint32_t dk = distinct_keys((uint32_t)ref); if (lane == (uint32_t)(__ffsll((long long)sm) - 1)) st_[12] += dk * (ANY ? 7u : 4u); }
+                if (STATS) { st_[0]++; const uint32_t dk = quad_distinct((uint32_t)ref), dw = wave_distinct((uint32_t)ref); if (lane == (uint32_t)(__ffsll((long long)sm) - 1)) { st_[12] += dk * (ANY ? 7u : 4u); st_[14] += dw * (ANY ? 7u : 4u); } }
                 gathers += ANY ? 7u : 4u;
                 if constexpr (ANY) {
                     // 4-wide node: up to four grandchild boxes per 128-byte record, order irrelevant for any-hit
@@ -594,7 +613,7 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
             for (int i = 0; i < count && !done; i += LEAFB) {
                 const float4 *t = sc.tris + (size_t)(first + (i >> 1)) * 5;
                 gathers += 5u * NP;
-                if (STATS) { const unsigned long long am = __ballot(1); const uint32_t dk = distinct_keys((uint32_t)(first + (i >> 1))); if (lane == (uint32_t)(__ffsll((long long)am) - 1)) st_[13] += dk * 5u * NP; }
+                if (STATS) { const unsigned long long am = __ballot(1); const uint32_t dk = quad_distinct((uint32_t)(first + (i >> 1))), dw = wave_distinct((uint32_t)(first + (i >> 1))); if (lane == (uint32_t)(__ffsll((long long)am) - 1)) { st_[13] += dk * 5u * NP; st_[15] += dw * 5u * NP; } }
                 float4 rec[NP][5];
 #pragma unroll
                 for (int k = 0; k < NP; ++k) { rec[k][0] = t[k * 5 + 0]; rec[k][1] = t[k * 5 + 1]; rec[k][2] = t[k * 5 + 2]; rec[k][3] = t[k * 5 + 3]; rec[k][4] = t[k * 5 + 4]; }
@@ -627,7 +646,7 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
     }
     if (STATS && lane == 0) st_[11] = clock64() - tStart_;
     if (STATS && stats) {
-        for (int q = 0; q < 14; ++q) {
+        for (int q = 0; q < 16; ++q) {
             unsigned long long v = st_[q];
             for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
             if (lane == 0 && v) atomicAdd(&stats[q], v);
@@ -860,24 +879,26 @@ __global__ void k_accum_tally(const uint32_t *counts, unsigned long long *acc, i
 }
 
 template <class Src, bool ANY>
-void launch_trace(hipStream_t st, int cus, int depth, const DevFrame *fr, const DevScene &hs, Src src, uint32_t *head, unsigned long long *tally,
+void launch_trace(hipStream_t st, int cus, int gridPct, int depth, const DevFrame *fr, const DevScene &hs, Src src, uint32_t *head, unsigned long long *tally,
                   unsigned long long *gatherLoads, TraceTune tune, unsigned long long *stats = nullptr) {
     // Stack entries: closest-hit defers one sibling per binary level (8 B each); any-hit walks 4-wide nodes and can
-    // defer three per two levels (4 B each).  Resident 256-thread blocks per CU follow from the LDS footprint.
-    const int need = ANY ? 3 * ((depth + 1) / 2) : depth;
-    const int s0 = ANY ? 24 : 16, s1 = ANY ? 36 : 24, s2 = ANY ? 48 : 32;
-    const int stack = need <= s0 ? s0 : (need <= s1 ? s1 : s2);
-    const int perCU = std::max(1, std::min(8, (160 * 1024) / (256 * stack * (ANY ? 4 : 8))));
+    // defer three per two levels (4 B each).  Resident 256-thread workgroups per CU follow from the LDS footprint and the kernel's
+    // registers: asked from the runtime per (kernel, stack size), the persistent grid is exactly what fits.
+    const int stack = std::max(4, ANY ? 3 * ((depth + 1) / 2) : depth);
+    const size_t ldsBytes = (size_t)256 * stack * (ANY ? 4 : 8);
     const float4 *nodes = ANY ? hs.w4 : hs.wnodesW;
-    dim3 g((unsigned)(cus * perCU)), b(256);
-#define RT_LAUNCH_TRACE(ST, LB) do { if (stats) hipLaunchKernelGGL((k_trace<Src, ANY, ST, LB, true>), g, b, 0, st, fr, nodes, hs.pairs, src, head, tally, gatherLoads, tune, stats); \
-        else hipLaunchKernelGGL((k_trace<Src, ANY, ST, LB, false>), g, b, 0, st, fr, nodes, hs.pairs, src, head, tally, gatherLoads, tune, (unsigned long long *)nullptr); } while (0)
-#define RT_LAUNCH_TRACE_LB(ST) do { if (tune.leafb >= 4) RT_LAUNCH_TRACE(ST, 4); else RT_LAUNCH_TRACE(ST, 2); } while (0)
-    if (stack == s0) RT_LAUNCH_TRACE_LB((ANY ? 24 : 16));
-    else if (stack == s1) RT_LAUNCH_TRACE_LB((ANY ? 36 : 24));
-    else RT_LAUNCH_TRACE_LB((ANY ? 48 : 32));
-#undef RT_LAUNCH_TRACE_LB
-#undef RT_LAUNCH_TRACE
+    auto go = [&](auto kernel) {
+        thread_local std::map<std::pair<const void *, size_t>, int> occ;   // the runtime's answer per (kernel, LDS bytes)
+        int &perCU = occ[{(const void *)kernel, ldsBytes}];
+        if (perCU == 0) {
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kernel, 256, ldsBytes) != hipSuccess || perCU < 1) perCU = 1;
+            perCU = std::min(perCU, 8);
+        }
+        const unsigned blocks = (unsigned)std::max(8, cus * perCU * gridPct / 100);
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), ldsBytes, st, fr, nodes, hs.pairs, src, head, tally, gatherLoads, tune, stack, stats);
+    };
+    if (stats) { if (tune.leafb >= 4) go(k_trace<Src, ANY, 4, true>); else go(k_trace<Src, ANY, 2, true>); }
+    else       { if (tune.leafb >= 4) go(k_trace<Src, ANY, 4, false>); else go(k_trace<Src, ANY, 2, false>); }
 }
 
 }  // namespace
@@ -1012,8 +1033,8 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
     W_TRY(hipMemsetAsync(w->heads, 0, (size_t)(1 + nChunks * 3) * kHeadWords * sizeof(uint32_t), st));
     // A tile-parallel rank traces 1/n of the rays and overlaps four frames: half-size persistent grids let the launches of
     // different frames share the CUs instead of queueing behind each other's long-ray tails (one rank of 8: 0.47 -> 0.43 ms/frame).
-    int traceBlocks = host.g.world > 1 ? std::max(8, w->cus / 2) : w->cus;
-    if (const char *e = getenv("RT_GRID_PCT")) traceBlocks = std::max(8, w->cus * atoi(e) / 100);
+    int gridPct = host.g.world > 1 ? 50 : 100;
+    if (const char *e = getenv("RT_GRID_PCT")) gridPct = std::max(1, atoi(e));
     if (getenv("RT_TRACE_STATS") && !w->stats) { W_TRY(hipMalloc(&w->stats, 64 * sizeof(unsigned long long))); W_TRY(hipMemset(w->stats, 0, 64 * sizeof(unsigned long long))); }
     unsigned long long *S = w->stats;
     const TraceTune tune = w->tune;
@@ -1031,7 +1052,7 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
     TraceTune tuneP = tune;   // primary rays: one run = one 8x8 pixel block; their cost varies strongly across the screen, so short runs
     if (tuneP.chunk == 0) tuneP.chunk = 64;   // balance the tail (stage alone 0.50 / 0.62 / 0.86 ms with runs of 64 / 128 / 256)
     if (const char *e = getenv("RT_CHUNK_PRIMARY")) tuneP.chunk = atoi(e);
-    launch_trace<PrimarySrc, false>(st, traceBlocks, treeDepth, dFrame, host.sc, ps, &wb.heads[0], w->acc + 2, w->acc + 8, tuneP, S ? S + 0 : nullptr);
+    launch_trace<PrimarySrc, false>(st, w->cus, gridPct, treeDepth, dFrame, host.sc, ps, &wb.heads[0], w->acc + 2, w->acc + 8, tuneP, S ? S + 0 : nullptr);
     rt_stage_end(ctx, ST_TRACE_PRIMARY, 1, st);
 
     rt_stage_begin(ctx, ST_POST_PRIMARY, st);
@@ -1067,7 +1088,7 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
             qg.o = wb.giO; qg.d = wb.giD; qg.tm = wb.giL; qg.liveCount = &wb.counts[1]; qg.c0 = c0; qg.cap = wb.CH; qg.stride = wb.CH; qg.slots = (uint32_t)SPP;
             qg.outT = wb.giT; qg.outTri = wb.giTri; qg.outOcc = nullptr;
             rt_stage_begin(ctx, ST_TRACE_GI, st);
-            launch_trace<QueueSrc, false>(st, traceBlocks, treeDepth, dFrame, host.sc, qg, &wb.heads[(size_t)(1 + c * 3 + 1) * kHeadWords], w->acc + 4, w->acc + 10, tune, S ? S + 32 : nullptr);
+            launch_trace<QueueSrc, false>(st, w->cus, gridPct, treeDepth, dFrame, host.sc, qg, &wb.heads[(size_t)(1 + c * 3 + 1) * kHeadWords], w->acc + 4, w->acc + 10, tune, S ? S + 32 : nullptr);
             rt_stage_end(ctx, ST_TRACE_GI, 1, st);
 
             rt_stage_begin(ctx, ST_GEN_GI, st);
@@ -1080,11 +1101,11 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
             qq.b.stride = wb.CH * (uint32_t)SPP; qq.b.slots = 6u;
             qq.b.outT = nullptr; qq.b.outTri = nullptr; qq.b.outOcc = wb.occ2;
             rt_stage_begin(ctx, ST_TRACE_SHADOW, st);
-            launch_trace<DualQueueSrc, true>(st, traceBlocks, treeDepth, dFrame, host.sc, qq, &wb.heads[(size_t)(1 + c * 3 + 0) * kHeadWords], w->acc + 3, w->acc + 9, tune, S ? S + 16 : nullptr);
+            launch_trace<DualQueueSrc, true>(st, w->cus, gridPct, treeDepth, dFrame, host.sc, qq, &wb.heads[(size_t)(1 + c * 3 + 0) * kHeadWords], w->acc + 3, w->acc + 9, tune, S ? S + 16 : nullptr);
             rt_stage_end(ctx, ST_TRACE_SHADOW, 1, st);
         } else {
             rt_stage_begin(ctx, ST_TRACE_SHADOW, st);
-            launch_trace<QueueSrc, true>(st, traceBlocks, treeDepth, dFrame, host.sc, q1, &wb.heads[(size_t)(1 + c * 3 + 0) * kHeadWords], w->acc + 3, w->acc + 9, tune, S ? S + 16 : nullptr);
+            launch_trace<QueueSrc, true>(st, w->cus, gridPct, treeDepth, dFrame, host.sc, q1, &wb.heads[(size_t)(1 + c * 3 + 0) * kHeadWords], w->acc + 3, w->acc + 9, tune, S ? S + 16 : nullptr);
             rt_stage_end(ctx, ST_TRACE_SHADOW, 1, st);
         }
         rt_stage_begin(ctx, ST_COMBINE, st);
@@ -1116,10 +1137,10 @@ int rt_wave_traced(RtWave *w, hipStream_t st, unsigned long long *out8, bool res
             const unsigned long long *q = v + k * 16;
             double rays = (double)std::max<unsigned long long>(out8[2 + k], 1);
             if (!quiet) fprintf(stderr, "[trace stats] %-13s rays %.3g | per ray: inner %.1f leaf %.1f tri %.1f | inner-phase lane util %.2f (%.3g wave-iters, %.0f cyc each) "
-                            "leaf-phase util %.2f (%.3g, %.0f cyc each) | refills %.3g (%.0f cyc each) | gather loads per ray %.0f, after merging equal records %.0f\n",
+                            "leaf-phase util %.2f (%.3g, %.0f cyc each) | refills %.3g (%.0f cyc each) | gather loads per ray %.0f, merged within lane quads %.0f (nodes %.0f + triangles %.0f), merged wave-wide %.0f (%.0f + %.0f)\n",
                     nm[k], rays, q[0] / rays, q[1] / rays, q[2] / rays, q[3] ? q[4] / (64.0 * q[3]) : 0.0, (double)q[3], q[3] ? (double)q[8] / q[3] : 0.0,
                     q[5] ? q[6] / (64.0 * q[5]) : 0.0, (double)q[5], q[5] ? (double)q[9] / q[5] : 0.0, (double)q[7], q[7] ? (double)q[10] / q[7] : 0.0,
-                    k < 3 ? out8[8 + k] / rays : 0.0, (q[12] + q[13]) / rays);
+                    k < 3 ? out8[8 + k] / rays : 0.0, (q[12] + q[13]) / rays, q[12] / rays, q[13] / rays, (q[14] + q[15]) / rays, q[14] / rays, q[15] / rays);
             if (k < 3) out8[11 + k] = q[12] + q[13];   // k: 0 primary, 1 shadow (+ bounce-shadow: one launch), 2 bounce
         }
         if (reset) W_TRY(hipMemset(w->stats, 0, sizeof v));
