@@ -331,7 +331,8 @@ int rt_create(const RtDeviceConfig *cfg, RtContext **out) {
     c->cfg = *cfg;
     // measured on MI355X (1080p / 4 spp): whole frame on one GPU 3.0 / 2.48 / 2.44 / 2.58 ms with 1 / 2 / 3 / 4 lanes; one rank of
     // eight (1/8 of the tiles, latency-bound stages) 0.92 / 0.64 / 0.56 / 0.51 ms
-    c->nLanes = cfg->worldSize > 1 ? 4 : 3;
+    // round 3, batches of eight frames with 75 % persistent grids: 1.76 / 1.75 ms per frame with 3 / 4 lanes
+    c->nLanes = 4;
     if (const char *e = getenv("RT_LANES")) c->nLanes = std::max(1, std::min(RT_MAX_LANES, atoi(e)));
     bool ok = hipMalloc(&c->dCounters, 16 * sizeof(unsigned long long)) == hipSuccess;
     for (int i = 0; ok && i < c->nLanes; ++i)
@@ -434,6 +435,7 @@ int rt_upload_bvh(RtContext *c, const float *nodes12, int nNodes, const float *t
             }
             const uint32_t orig = (uint32_t)(n.first + t);
             std::memcpy(&r[18], &orig, 4);
+            if (t + 1 >= n.count) std::memcpy(&r[9], &orig, 4);   // a record with one triangle: the index again in the unused tenth float (3-load fetch)
             pairs.insert(pairs.end(), r, r + 20);
         }
     }
@@ -668,7 +670,8 @@ static int render_frames_impl(RtContext *c, const RtUniforms *uIn, int batch, co
     if (pipeline == RT_PIPELINE_WAVEFRONT && !(fr.u.useBVH == 1)) pipeline = RT_PIPELINE_MEGAKERNEL;   // analytic scene: pure ALU, megakernel only
     if (batch > 1 && pipeline != RT_PIPELINE_WAVEFRONT) return fail(c, RT_ERR_STATE, "internal: a frame batch reached the megakernel");
     if (pipeline == RT_PIPELINE_WAVEFRONT) {
-        int rc = rt_wave_render(c->wave[lane], c, st, c->dFrame[lane], fr, tg, c->dCounters, count, std::max(c->treeDepth, 1), c->nLanes > 1 ? c->evDone[prevLane] : nullptr);
+        int rc = rt_wave_render(c->wave[lane], c, st, c->dFrame[lane], fr, tg, c->dCounters, count, std::max(c->treeDepth, 1), c->nLanes > 1 ? c->evDone[prevLane] : nullptr,
+                                (size_t)c->nInner * 64 + c->nWide4 * 128 + c->nPairs * 80 < ((size_t)32 << 20));
         if (rc != RT_OK) return fail(c, rc, "wavefront pipeline: %s", rt_wave_error(c->wave[lane]));
     } else {
         if (c->nLanes > 1) HIP_TRY(c, hipStreamWaitEvent(st, c->evDone[prevLane], 0));   // the megakernel reads the history from its first instruction on

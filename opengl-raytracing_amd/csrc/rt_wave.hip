@@ -398,10 +398,11 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
     src.prepare();
     const uint32_t n = src.size();
     const uint32_t lane = threadIdx.x & 63;
-    // run length: RT_CHUNK, else about a third of a wave's share of the queue, in [128, 256] rays (measured on MI355X, 1080p / 4 spp:
-    // whole frame 2.42 / 2.26 / 2.18 / 2.20 ms with runs of 64 / 128 / 256 / 512; one rank of eight 0.51 / 0.48 / 0.52 / 0.55)
+    // run length: RT_CHUNK, else about a third of a wave's share of the queue, in [128, 384] rays (measured on MI355X, 1080p / 4 spp:
+    // whole frame 2.42 / 2.26 / 2.18 / 2.20 ms with runs of 64 / 128 / 256 / 512; one rank of eight 0.51 / 0.48 / 0.52 / 0.55; round 3, batches
+    // of eight frames, 1.83 / 1.78 / 1.79 ms per frame with runs of at most 256 / 384 / 512)
     const uint32_t runLen = tune.chunk > 0 ? (uint32_t)max(tune.chunk, 8)
-                                           : min(256u, max(128u, ((n / (3u * 4u * gridDim.x) + 63u) / 64u) * 64u));
+                                           : min(384u, max(128u, ((n / (3u * 4u * gridDim.x) + 63u) / 64u) * 64u));
 
     // per-lane ray state
     V3 ro = mk3(0.0f), rd = mk3(0.0f), rdInv = mk3(0.0f);
@@ -610,7 +611,9 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
             // fetch LEAFB/2 of them at a time so that the gather round trips of one group overlap (the array is padded, so no
             // bounds branch); test in leaf order.
             constexpr int NP = LEAFB / 2;
-            for (int i = 0; i < count && !done; i += LEAFB) {
+            // full groups of LEAFB triangles (LEAFB/2 pair records of 5 loads each) ...
+            const int nFull = (LEAFB == 2) ? (count & ~1) : count;   // LEAFB == 2: an odd last triangle is left to the 3-load tail below
+            for (int i = 0; i < nFull && !done; i += LEAFB) {
                 const float4 *t = sc.tris + (size_t)(first + (i >> 1)) * 5;
                 gathers += 5u * NP;
                 if (STATS) { const unsigned long long am = __ballot(1); const uint32_t dk = quad_distinct((uint32_t)(first + (i >> 1))), dw = wave_distinct((uint32_t)(first + (i >> 1))); if (lane == (uint32_t)(__ffsll((long long)am) - 1)) { st_[13] += dk * 5u * NP; st_[15] += dw * 5u * NP; } }
@@ -631,6 +634,21 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
                         if (ANY) done = true;
                         else { tBest = tt; triBest = (int)f2u(r4.z) + (k & 1); }
                     }
+                }
+            }
+            // ... then the odd last triangle of the leaf: its record holds ONE triangle, whose nine floats (and, for closest-hit rays, its
+            // index, repeated in the otherwise unused tenth float) sit in the first three 16-byte pieces: 3 gather loads instead of 5
+            // (every leaf of the bench mesh has 5 triangles: 13 loads per leaf visit instead of 15).
+            if (LEAFB == 2 && (count & 1) && !done) {
+                const float4 *t = sc.tris + (size_t)(first + (count >> 1)) * 5;
+                gathers += 3u;
+                if (STATS) { const unsigned long long am = __ballot(1); const uint32_t dk = quad_distinct((uint32_t)(first + (count >> 1))), dw = wave_distinct((uint32_t)(first + (count >> 1))); if (lane == (uint32_t)(__ffsll((long long)am) - 1)) { st_[13] += dk * 3u; st_[15] += dw * 3u; } st_[2]++; }
+                float4 r0 = t[0], r1 = t[1], r2 = t[2];
+                pin(r0); pin(r1); pin(r2);
+                float tt;
+                if (tri_hit(ro, rd, mk3(r0.x, r0.y, r0.z), mk3(r0.w, r1.x, r1.y), mk3(r1.z, r1.w, r2.x), eps, tBest, tt)) {
+                    if (ANY) done = true;
+                    else { tBest = tt; triBest = (int)f2u(r2.y); }
                 }
             }
             if (ANY && done) {
@@ -957,7 +975,7 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
     } while (0)
 
 int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dFrame, const DevFrame &host, Targets tg,
-                   unsigned long long *, bool count, int treeDepth, hipEvent_t evPrevDone) {
+                   unsigned long long *, bool count, int treeDepth, hipEvent_t evPrevDone, bool cacheResident) {
     if (count) { w->err = "work counters are produced by the megakernel pipeline (RT_PIPELINE_MEGAKERNEL)"; return RT_ERR_UNSUPPORTED; }
     const RtUniforms &u = host.u;
     const int batch = std::max(host.g.batch, 1);
@@ -1031,10 +1049,17 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
 
     W_TRY(hipMemsetAsync(w->counts, 0, (size_t)(64 + nChunks) * sizeof(uint32_t), st));
     W_TRY(hipMemsetAsync(w->heads, 0, (size_t)(1 + nChunks * 3) * kHeadWords * sizeof(uint32_t), st));
-    // A tile-parallel rank traces 1/n of the rays and overlaps four frames: half-size persistent grids let the launches of
-    // different frames share the CUs instead of queueing behind each other's long-ray tails (one rank of 8: 0.47 -> 0.43 ms/frame).
-    int gridPct = host.g.world > 1 ? 50 : 100;
+    // Persistent grids smaller than what fits, for the two queue launches of a cache-resident scene: they run near the vector L1's access
+    // rate (0.81 accesses per clock and CU, PMC), which four and a half workgroups per CU sustain as well as six, and the
+    // registers left free let the shading kernels of the other frame lanes run beside them instead of waiting for a persistent grid to
+    // drain (kernel timeline, profiles/r03_timeline.txt: k_combine in flight 78 % of the time for 8 % of the work).  One GPU, batches of
+    // eight frames: 1.83 -> 1.76 ms per frame.  Not for the primary launch (latency-bound: 0.24 -> 0.27 ms at 75 %) and not for a
+    // scene that misses L2 (1 M triangles: any-hit launch 15.2 -> 16.1 ms at 75 % -- it needs every wave to cover the fabric's latency).
+    // A tile-parallel rank traces 1/n of the rays and overlaps four batches: half-size grids (one rank of 8: 0.47 -> 0.43 ms/frame).
+    int gridPct = host.g.world > 1 ? 50 : (cacheResident ? 75 : 100);
     if (const char *e = getenv("RT_GRID_PCT")) gridPct = std::max(1, atoi(e));
+    int gridPctPrimary = host.g.world > 1 ? gridPct : 100;
+    if (const char *e = getenv("RT_GRID_PCT_PRIMARY")) gridPctPrimary = std::max(1, atoi(e));
     if (getenv("RT_TRACE_STATS") && !w->stats) { W_TRY(hipMalloc(&w->stats, 64 * sizeof(unsigned long long))); W_TRY(hipMemset(w->stats, 0, 64 * sizeof(unsigned long long))); }
     unsigned long long *S = w->stats;
     const TraceTune tune = w->tune;
@@ -1052,7 +1077,7 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
     TraceTune tuneP = tune;   // primary rays: one run = one 8x8 pixel block; their cost varies strongly across the screen, so short runs
     if (tuneP.chunk == 0) tuneP.chunk = 64;   // balance the tail (stage alone 0.50 / 0.62 / 0.86 ms with runs of 64 / 128 / 256)
     if (const char *e = getenv("RT_CHUNK_PRIMARY")) tuneP.chunk = atoi(e);
-    launch_trace<PrimarySrc, false>(st, w->cus, gridPct, treeDepth, dFrame, host.sc, ps, &wb.heads[0], w->acc + 2, w->acc + 8, tuneP, S ? S + 0 : nullptr);
+    launch_trace<PrimarySrc, false>(st, w->cus, gridPctPrimary, treeDepth, dFrame, host.sc, ps, &wb.heads[0], w->acc + 2, w->acc + 8, tuneP, S ? S + 0 : nullptr);
     rt_stage_end(ctx, ST_TRACE_PRIMARY, 1, st);
 
     rt_stage_begin(ctx, ST_POST_PRIMARY, st);

@@ -11,9 +11,10 @@ RtWave *rt_wave_create(int computeUnits);
 void rt_wave_destroy(RtWave *w);
 const char *rt_wave_error(const RtWave *w);
 // Renders one frame of a BVH scene into `tg` on `stream`.  `host` is the host copy of *dFrame.  Only the final temporal
-// resolve waits for `evPrevDone` (the previous frame's completion event, may be null).
+// resolve waits for `evPrevDone` (the previous frame's completion event, may be null).  cacheResident: the BVH arrays fit the 32 MB of L2
+// (sizes the persistent grids, see rt_wave_render).
 int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t stream, const rtd::DevFrame *dFrame, const rtd::DevFrame &host,
-                   rtd::Targets tg, unsigned long long *counters, bool count, int treeDepth, hipEvent_t evPrevDone);
+                   rtd::Targets tg, unsigned long long *counters, bool count, int treeDepth, hipEvent_t evPrevDone, bool cacheResident);
 
 // tallies accumulated since the last reset, 16 words: [0] candidate pixels [1] hit pixels [2] primary [3] shadow+AO
 // [4] bounce [5] bounce-shadow rays actually traversed, [6] frames, [8..10] 16-byte gather loads issued by the primary /
