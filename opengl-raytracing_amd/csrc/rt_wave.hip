@@ -327,6 +327,11 @@ struct DualQueueSrc {
 // one gather round trip into two or three dependent ones.  pin() makes a loaded record "used" right after the loads were
 // issued, so the whole group is in flight together.
 RT_DEV void pin(float4 &v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+// The traversal kernels pin whole 128-bit registers tuples: with four 32-bit constraints the register allocator is free to move the
+// components apart from the tuple the load wrote, and did (19 v_mov per 4-wide node visit, about a tenth of the step's vector instructions --
+// and these launches are bound by vector-instruction issue).
+typedef float v4f __attribute__((ext_vector_type(4)));
+RT_DEV void pin(v4f &v) { asm volatile("" : "+v"(v)); }
 
 // lane position of the n-th (0-based) set bit of m (n < popcount(m)): binary search over popcounts
 RT_DEV uint32_t nth_set(unsigned long long m, uint32_t n) {
@@ -370,7 +375,7 @@ RT_DEV uint32_t quad_distinct(uint32_t key) {
 constexpr uint32_t kShards = 64, kShardStride = 32;   // cursor shards per trace launch, uint32 words between them (128 B)
 constexpr uint32_t kHeadWords = kShards * kShardStride;
 
-struct TraceTune { int refillMin; int minSearch; int chunk; int leafb; int skipTraversal; };   // skipTraversal: diagnostic (RT_DEBUG_SKIP_TRAVERSAL)
+struct TraceTune { int refillMin; int minSearch; int chunk; int leafb; int skipTraversal; int quadRefill; };   // skipTraversal: diagnostic (RT_DEBUG_SKIP_TRAVERSAL)
 
 template <bool ANY> struct StackOf { typedef StackEntry type; };          // closest: {deferred child, its entry distance}
 template <> struct StackOf<true> { typedef uint32_t type; };              // any-hit: the pop-time cull never fires (tMax is constant)
@@ -456,7 +461,14 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
         // runs s, s+kShards, ...; a wave draws from its home shard and steals round-robin once that is dry.  (One shared
         // cursor word sustains only ~88 M atomics/s on MI355X -- per-refill, then per-run atomics on a single word
         // bounded earlier versions of this kernel; a purely static deal leaves the bounce-ray tail unbalanced.)
-        unsigned long long idleMask = __ballot(!active);
+        // quadRefill: only quads of four adjacent lanes that are idle together take new rays, four consecutive ones: the vector L1 merges
+        // the loads of adjacent lanes that stand on the same record (quad_distinct), and rays dealt together walk the top of the tree together
+        auto whole_quads = [&](unsigned long long m) {
+            if (!tune.quadRefill) return m;
+            unsigned long long q = m & (m >> 1) & (m >> 2) & (m >> 3) & 0x1111111111111111ull;
+            return q | (q << 1) | (q << 2) | (q << 3);
+        };
+        unsigned long long idleMask = whole_quads(__ballot(!active));
         int nIdle = __popcll(idleMask);
         if (!exhausted && nIdle >= tune.refillMin) {
             const unsigned long long tR_ = STATS ? clock64() : 0ull;
@@ -526,7 +538,7 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
                 }
                 // all live slots taken: the window is used up; else everything before the first live slot left over
                 runNext += nLiveW <= nIdleL ? window : nth_set(liveMask, nTake);
-                idleLeft = __ballot(!active);                                  // root misses may draw again
+                idleLeft = whole_quads(__ballot(!active));                     // root misses may draw again
             }
             if (STATS && lane == 0) st_[10] += clock64() - tR_;
             continue;   // lanes that drew a dead slot or a root miss may draw again
@@ -550,7 +562,8 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
                     // 4-wide node: up to four grandchild boxes per 128-byte record, order irrelevant for any-hit
                     const float4 *nd = nodes + (size_t)ref * 8;
                     // component-wise: [min.x x4][min.y x4][min.z x4][max.x x4][max.y x4][max.z x4][ref x4] = 7 loads, 8th piece unused
-                    float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3], q4 = nd[4], q5 = nd[5], q6 = nd[6];
+                    const v4f *ndv = reinterpret_cast<const v4f *>(nd);
+                    v4f q0 = ndv[0], q1 = ndv[1], q2 = ndv[2], q3 = ndv[3], q4 = ndv[4], q5 = ndv[5], q6 = ndv[6];
                     pin(q0); pin(q1); pin(q2); pin(q3); pin(q4); pin(q5); pin(q6);
                     int r0 = (int)f2u(q6.x), r1 = (int)f2u(q6.y), r2 = (int)f2u(q6.z), r3 = (int)f2u(q6.w);
                     float t0, t1, t2, t3;
@@ -577,11 +590,12 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
                     else ref = nxt;
                 } else {
                     const float4 *nd = nodes + (size_t)ref * 4;
-                    float4 a = nd[0], b = nd[1], c = nd[2], d = nd[3];
+                    const v4f *ndv = reinterpret_cast<const v4f *>(nd);
+                    v4f a = ndv[0], b = ndv[1], c = ndv[2], d = ndv[3];
                     pin(a); pin(b); pin(c); pin(d);
                     float tL, tR;
-                    bool hitL = slab(ro, rdInv, f4xyz(a), f4xyz(b), tL) && tL <= tBest;
-                    bool hitR = slab(ro, rdInv, f4xyz(c), f4xyz(d), tR) && tR <= tBest;
+                    bool hitL = slab(ro, rdInv, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), tL) && tL <= tBest;
+                    bool hitR = slab(ro, rdInv, mk3(c.x, c.y, c.z), mk3(d.x, d.y, d.z), tR) && tR <= tBest;
                     int refL = (int)f2u(a.w), refR = (int)f2u(b.w);
                     if (hitL && hitR) {
                         bool leftFirst = tL < tR;
@@ -617,14 +631,15 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
                 const float4 *t = sc.tris + (size_t)(first + (i >> 1)) * 5;
                 gathers += 5u * NP;
                 if (STATS) { const unsigned long long am = __ballot(1); const uint32_t dk = quad_distinct((uint32_t)(first + (i >> 1))), dw = wave_distinct((uint32_t)(first + (i >> 1))); if (lane == (uint32_t)(__ffsll((long long)am) - 1)) { st_[13] += dk * 5u * NP; st_[15] += dw * 5u * NP; } }
-                float4 rec[NP][5];
+                const v4f *tv = reinterpret_cast<const v4f *>(t);
+                v4f rec[NP][5];
 #pragma unroll
-                for (int k = 0; k < NP; ++k) { rec[k][0] = t[k * 5 + 0]; rec[k][1] = t[k * 5 + 1]; rec[k][2] = t[k * 5 + 2]; rec[k][3] = t[k * 5 + 3]; rec[k][4] = t[k * 5 + 4]; }
+                for (int k = 0; k < NP; ++k) { rec[k][0] = tv[k * 5 + 0]; rec[k][1] = tv[k * 5 + 1]; rec[k][2] = tv[k * 5 + 2]; rec[k][3] = tv[k * 5 + 3]; rec[k][4] = tv[k * 5 + 4]; }
 #pragma unroll
                 for (int k = 0; k < NP; ++k) { pin(rec[k][0]); pin(rec[k][1]); pin(rec[k][2]); pin(rec[k][3]); pin(rec[k][4]); }
 #pragma unroll
                 for (int k = 0; k < LEAFB; ++k) {
-                    const float4 &r0 = rec[k >> 1][0], &r1 = rec[k >> 1][1], &r2 = rec[k >> 1][2], &r3 = rec[k >> 1][3], &r4 = rec[k >> 1][4];
+                    const v4f &r0 = rec[k >> 1][0], &r1 = rec[k >> 1][1], &r2 = rec[k >> 1][2], &r3 = rec[k >> 1][3], &r4 = rec[k >> 1][4];
                     const V3 v0 = (k & 1) ? mk3(r2.y, r2.z, r2.w) : mk3(r0.x, r0.y, r0.z);
                     const V3 e1 = (k & 1) ? mk3(r3.x, r3.y, r3.z) : mk3(r0.w, r1.x, r1.y);
                     const V3 e2 = (k & 1) ? mk3(r3.w, r4.x, r4.y) : mk3(r1.z, r1.w, r2.x);
@@ -643,7 +658,8 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
                 const float4 *t = sc.tris + (size_t)(first + (count >> 1)) * 5;
                 gathers += 3u;
                 if (STATS) { const unsigned long long am = __ballot(1); const uint32_t dk = quad_distinct((uint32_t)(first + (count >> 1))), dw = wave_distinct((uint32_t)(first + (count >> 1))); if (lane == (uint32_t)(__ffsll((long long)am) - 1)) { st_[13] += dk * 3u; st_[15] += dw * 3u; } st_[2]++; }
-                float4 r0 = t[0], r1 = t[1], r2 = t[2];
+                const v4f *tv = reinterpret_cast<const v4f *>(t);
+                v4f r0 = tv[0], r1 = tv[1], r2 = tv[2];
                 pin(r0); pin(r1); pin(r2);
                 float tt;
                 if (tri_hit(ro, rd, mk3(r0.x, r0.y, r0.z), mk3(r0.w, r1.x, r1.y), mk3(r1.z, r1.w, r2.x), eps, tBest, tt)) {
@@ -928,7 +944,7 @@ struct RtWave {
     std::string err;
     int cus = 256;
     size_t budgetBytes = (size_t)8 << 30;   // ray-queue budget per context; 288 GB of HBM make this cheap
-    TraceTune tune{32, 16, 0, 2, 0};   // chunk 0 = run length chosen in the kernel from the queue size
+    TraceTune tune{32, 16, 0, 2, 0, 0};   // chunk 0 = run length chosen in the kernel from the queue size
     // allocations
     size_t slotsCap = 0;      // per-frame arrays sized for this many pixel slots
     size_t chunkBytes = 0;    // bytes of the per-chunk arena
@@ -951,6 +967,7 @@ RtWave *rt_wave_create(int cus) {
     if (const char *e = getenv("RT_LEAFB")) w->tune.leafb = atoi(e);
     if (const char *e = getenv("RT_MIN_SEARCH")) w->tune.minSearch = std::max(0, std::min(64, atoi(e)));
     if (const char *e = getenv("RT_CHUNKS_FROM_SLOTS")) w->chunksFromSlots = atoi(e) != 0;
+    if (const char *e = getenv("RT_QUAD_REFILL")) w->tune.quadRefill = atoi(e) != 0;
     return w;
 }
 void rt_wave_destroy(RtWave *w) {
