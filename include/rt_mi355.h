@@ -105,7 +105,7 @@ typedef struct RtCounters {
 } RtCounters;
 
 typedef enum RtPipeline {
-    RT_PIPELINE_AUTO = 0,       /* wavefront pipeline for BVH scenes, megakernel for the analytic scene */
+    RT_PIPELINE_AUTO = 0,       /* wavefront pipeline for BVH scenes, megakernel for the analytic scene, staged replay for the hybrid extension */
     RT_PIPELINE_MEGAKERNEL = 1, /* one thread per pixel, the whole fragment program in one kernel */
     RT_PIPELINE_WAVEFRONT = 2   /* staged: primary -> ray generation -> persistent traversal -> combine */
 } RtPipeline;
@@ -188,7 +188,8 @@ int rt_render_ray(RtContext *ctx, const RtRenderParams *params, const RtCamera *
  * branch of getMaterial, rt_materials.glsl:123-124), so the glass sphere refracts it, the mirror reflects it, it casts and receives
  * shadows, AO and GI.  giBounces > 1 lengthens the analytic GI path (oneBounceGIAnalytic) to that many diffuse bounces.  With an empty
  * BVH and giBounces == 1 this is the reference's analytic mode bit for bit.  Parity: this repository's own oracle only.
- * Megakernel pipeline. */
+ * Pipelines: staged (RT_PIPELINE_AUTO / _WAVEFRONT: shading passes that replay answered mesh queries and queue the open ones, persistent
+ * closest-hit traversal launches in between; csrc/rt_hybrid.hip) or the megakernel (RT_PIPELINE_MEGAKERNEL); same frames bit for bit. */
 #define RT_SCENE_HYBRID 2
 typedef struct RtExtension { int32_t giBounces; int32_t reserved[3]; } RtExtension;
 int rt_set_extension(RtContext *ctx, const RtExtension *ext);   /* applies to the frames rendered after the call */

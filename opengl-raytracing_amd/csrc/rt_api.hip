@@ -65,6 +65,8 @@ struct RtContext {
     void *dStaging = nullptr;
     size_t stagingBytes = 0;
     RtWave *wave[RT_MAX_LANES] = {};
+    RtHybrid *hybrid[RT_MAX_LANES] = {};   // EXTENSION: staged hybrid pipeline, created on first use
+    int cus = 256;
     int giBounces = 1;   // EXTENSION, rt_set_extension
     // tile-parallel exchange owned by the library (rt_comm.cpp): RCCL communicator + per-lane gather buffers on the gathering rank
     void *comm = nullptr;                               // ncclComm_t
@@ -344,6 +346,7 @@ int rt_create(const RtDeviceConfig *cfg, RtContext **out) {
     }
     c->stream = c->lanes[0];
     (void)hipMemset(c->dCounters, 0, 16 * sizeof(unsigned long long));
+    c->cus = prop.multiProcessorCount;
     for (int i = 0; i < c->nLanes; ++i) c->wave[i] = rt_wave_create(prop.multiProcessorCount);
     c->lastStream = c->stream;
     int rc = rt_upload_env(c, nullptr, 0, 0);   // dummy cube map like Application::initState (application.cpp:281)
@@ -358,7 +361,7 @@ void rt_destroy(RtContext *c) {
     (void)sync_all(c);
     (void)rt_comm_destroy(c);
     free_targets(c);
-    for (int i = 0; i < RT_MAX_LANES; ++i) { if (c->wave[i]) rt_wave_destroy(c->wave[i]); if (c->dFrame[i]) (void)hipFree(c->dFrame[i]); if (c->evDone[i]) (void)hipEventDestroy(c->evDone[i]); }
+    for (int i = 0; i < RT_MAX_LANES; ++i) { if (c->hybrid[i]) rt_hybrid_destroy(c->hybrid[i]); if (c->wave[i]) rt_wave_destroy(c->wave[i]); if (c->dFrame[i]) (void)hipFree(c->dFrame[i]); if (c->evDone[i]) (void)hipEventDestroy(c->evDone[i]); }
     for (int i = 0; i < RT_MAX_LANES; ++i) if (c->lanes[i]) (void)hipStreamDestroy(c->lanes[i]);   // c->stream is lanes[0]
     if (c->dWNodes) (void)hipFree(c->dWNodes);
     if (c->dW4) (void)hipFree(c->dW4);
@@ -669,7 +672,13 @@ static int render_frames_impl(RtContext *c, const RtUniforms *uIn, int batch, co
     if (pipeline == RT_PIPELINE_AUTO) pipeline = (fr.u.useBVH == 1 && fr.sc.hasBVH && !count) ? RT_PIPELINE_WAVEFRONT : RT_PIPELINE_MEGAKERNEL;
     if (pipeline == RT_PIPELINE_WAVEFRONT && !(fr.u.useBVH == 1)) pipeline = RT_PIPELINE_MEGAKERNEL;   // analytic scene: pure ALU, megakernel only
     if (batch > 1 && pipeline != RT_PIPELINE_WAVEFRONT) return fail(c, RT_ERR_STATE, "internal: a frame batch reached the megakernel");
-    if (pipeline == RT_PIPELINE_WAVEFRONT) {
+    // EXTENSION: the hybrid scene in stages (rt_hybrid.hip) unless the megakernel was asked for; same frames bit for bit
+    const bool staged = c->cfg.pipeline != RT_PIPELINE_MEGAKERNEL && fr.u.useBVH == RT_SCENE_HYBRID && fr.sc.hasBVH && !count;
+    if (staged) {
+        if (!c->hybrid[0]) c->hybrid[0] = rt_hybrid_create(c->cus);   // one arena for all lanes: the passes synchronise with the host anyway
+        int rc = rt_hybrid_render(c->hybrid[0], c, st, c->dFrame[lane], fr, tg, std::max(c->treeDepth, 1), c->nLanes > 1 ? c->evDone[prevLane] : nullptr);
+        if (rc != RT_OK) return fail(c, rc, "staged hybrid pipeline: %s", rt_hybrid_error(c->hybrid[0]));
+    } else if (pipeline == RT_PIPELINE_WAVEFRONT) {
         int rc = rt_wave_render(c->wave[lane], c, st, c->dFrame[lane], fr, tg, c->dCounters, count, std::max(c->treeDepth, 1), c->nLanes > 1 ? c->evDone[prevLane] : nullptr,
                                 (size_t)c->nInner * 64 + c->nWide4 * 128 + c->nPairs * 80 < ((size_t)32 << 20));
         if (rc != RT_OK) return fail(c, rc, "wavefront pipeline: %s", rt_wave_error(c->wave[lane]));

@@ -80,10 +80,47 @@ __device__ __noinline__ bool traceAnalyticCore(const RtUniforms &u, V3 ro, V3 rd
 // Scene query of the analytic shading code.  Reference modes: traceAnalyticCore.  EXTENSION uUseBVH == RT_SCENE_HYBRID (SURVEY.md 8d
 // config 3 "run B"): the BVH mesh is one more object at the end of the list, under the list's own rule (strict <: an earlier object
 // wins a tie); its hit is what traceBVH returns (geometric normal), its material id MAT_MESH.
+// `geometric`: the caller builds later rays from this hit (primary, bounce, reflection, refraction); false for visibility / AO queries,
+// whose answers only scale radiance.  Only the staged pipeline looks at it.
 template <bool COUNT>
-__device__ __noinline__ bool traceScene(const Frag &F, V3 ro, V3 rd, bool includeGlass, bool includeMarker, Hit &hit, Work &w) {
+__device__ __noinline__ bool traceScene(const Frag &F, V3 ro, V3 rd, bool includeGlass, bool includeMarker, Hit &hit, Work &w, bool geometric = false) {
     const RtUniforms &u = *F.u;
     bool any = traceAnalyticCore<COUNT>(u, ro, rd, includeGlass, includeMarker, hit, w);
+    if (u.useBVH == RT_SCENE_HYBRID && F.rp) {
+        // Staged: the mesh query is answered from the log of earlier passes, or queued.  A ray that misses the mesh's root box is a miss at
+        // once -- the same test bvh_closest starts with -- and takes no query number, in every pass alike.
+        Replay &R = *F.rp;
+        const DevScene &sc = *F.sc;
+        float tmin;
+        const V3 rdInv = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+        if (sc.hasBVH && slab(ro, rdInv, ld3(sc.rootMin), ld3(sc.rootMax), tmin) && !(tmin > u.inf)) {
+            const uint32_t q = R.q++;
+            if (q < R.known) {
+                const size_t a = (size_t)q * R.stride + R.thread;
+                const int tri = R.logTri[a];
+                const float t = R.logT[a];
+                if (tri >= 0 && t < hit.t) {
+                    hit.t = t;
+                    hit.p = ro + rd * t;
+                    hit.n = tri_normal(sc, tri);
+                    hit.mat = MAT_MESH;
+                    any = true;
+                }
+            } else {
+                R.pending++;
+                if (!R.poisoned) {
+                    if (q < R.qmax) {
+                        const size_t a = (size_t)q * R.stride + R.thread;
+                        R.o[a] = make_float4(ro.x, ro.y, ro.z, 0.0f);
+                        R.d[a] = make_float4(rd.x, rd.y, rd.z, 0.0f);
+                        R.recEnd = q + 1u;
+                    } else R.overflow = true;
+                    if (geometric) R.poisoned = true;
+                }
+            }
+        }
+        return any;
+    }
     if (u.useBVH == RT_SCENE_HYBRID && F.stk) {
         float t;
         int tri;
@@ -198,7 +235,7 @@ __device__ __noinline__ V3 oneBounceGIAnalytic(const Frag &F, const Hit &h0, int
         if (cosTheta <= 0.0f) break;
         V3 origin = h.p + N0 * u.eps;
         Hit h1;
-        bool hit1 = traceScene<COUNT>(F, origin, wi, true, true, h1, w);
+        bool hit1 = traceScene<COUNT>(F, origin, wi, true, true, h1, w, true);
         V3 Li = hit1 ? directLightA<COUNT>(F, h1, frame, -wi, w) : sky<COUNT>(F, wi, w);
         V3 TF = T * (mat0.albedo * (cosTheta / u.pi));
         result = result + TF * Li;
@@ -225,7 +262,7 @@ RT_DEV V3 shadeGlass(const Frag &F, const Hit &h, V3 wo, const MaterialProps &ma
     V3 reflectLocal = reflectEnv;
     {
         Hit hRefl;
-        if (traceScene<COUNT>(F, h.p + R * u.eps, R, false, true, hRefl, w)) {
+        if (traceScene<COUNT>(F, h.p + R * u.eps, R, false, true, hRefl, w, true)) {
             V3 V2v = normalize(camPos - hRefl.p);
             reflectLocal = directLightA<COUNT>(F, hRefl, frame, V2v, w);
         }
@@ -234,7 +271,7 @@ RT_DEV V3 shadeGlass(const Frag &F, const Hit &h, V3 wo, const MaterialProps &ma
     V3 straightCol;
     {
         Hit hS;
-        if (traceScene<COUNT>(F, h.p + I * u.eps, I, false, true, hS, w)) {
+        if (traceScene<COUNT>(F, h.p + I * u.eps, I, false, true, hS, w, true)) {
             V3 V2v = normalize(camPos - hS.p);
             straightCol = directLightA<COUNT>(F, hS, frame, V2v, w);
         } else straightCol = sky<COUNT>(F, I, w);
@@ -247,7 +284,7 @@ RT_DEV V3 shadeGlass(const Frag &F, const Hit &h, V3 wo, const MaterialProps &ma
         V3 T = normalize(mix(I, T_phys, distortionStrength));
         Hit hR;
         V3 bentCol;
-        if (traceScene<COUNT>(F, h.p + T * u.eps, T, false, true, hR, w)) {
+        if (traceScene<COUNT>(F, h.p + T * u.eps, T, false, true, hR, w, true)) {
             V3 V2v = normalize(camPos - hR.p);
             bentCol = directLightA<COUNT>(F, hR, frame, V2v, w);
         } else bentCol = sky<COUNT>(F, T, w);
@@ -267,7 +304,7 @@ RT_DEV V3 shadeMirror(const Frag &F, const Hit &h, V3 wo, const MaterialProps &m
     V3 R = reflect(I, N);
     V3 org = h.p + R * u.eps;
     Hit h2;
-    bool hit2 = traceScene<COUNT>(F, org, R, true, true, h2, w);
+    bool hit2 = traceScene<COUNT>(F, org, R, true, true, h2, w, true);
     V3 col;
     if (hit2) {
         col = directLightA<COUNT>(F, h2, frame, -R, w);

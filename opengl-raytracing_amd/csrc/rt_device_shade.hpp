@@ -263,6 +263,24 @@ RT_DEV V3 tri_normal(const DevScene &sc, int tri) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// EXTENSION (hybrid scene, staged): replay state of one (pixel, sample) thread of rt_hybrid.hip.  The analytic shading code asks for mesh
+// hits through ONE function (traceScene); staged, that function answers from a log of earlier passes and records what it cannot answer yet
+// into a ray queue that a persistent traversal launch then traces.  Queries are numbered in program order (only those whose ray meets
+// the mesh's root box count), entry q of thread i lives at [q * stride + i] of every array.
+struct Replay {
+    uint32_t q = 0;           // queries met so far in this pass
+    uint32_t known = 0;       // queries answered by earlier passes
+    uint32_t recEnd = 0;      // one past the last query recorded in this pass
+    uint32_t pending = 0;     // queries without an answer met in this pass (recorded or not)
+    bool poisoned = false;    // an unanswered query that later geometry depends on was met: what follows it is not recorded
+    bool overflow = false;    // more than qmax queries
+    uint32_t thread = 0, stride = 0, qmax = 0;
+    float4 *o = nullptr, *d = nullptr;
+    const float *logT = nullptr;
+    const int *logTri = nullptr;
+};
+
+// ---------------------------------------------------------------------------------------------
 // Per-fragment context.
 struct Frag {
     const RtUniforms *u;   // kernel-argument copy (uniform across the grid)
@@ -271,6 +289,7 @@ struct Frag {
     // EXTENSION (hybrid scene, RT_SCENE_HYBRID): this lane's traversal stack, so that the analytic scene query can also walk the BVH;
     // bounces of the analytic / hybrid GI path (1 = the reference).  Unused in the reference's two modes.
     StackEntry *stk = nullptr;
+    Replay *rp = nullptr;   // staged hybrid pipeline (rt_hybrid.hip); null in the megakernel
     int giBounces = 1;
     // uFrameIndex of THIS fragment's frame.  The reference's value for a single frame; with frame batching (rt_render_frames: K frames of
     // a static camera in one set of launches) the frames of a batch differ in it -- and in the jitter, see primaryDirJ -- and in nothing else.

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void k_mega(const DevFrame *__restrict__ fr, T
             for (int s = 0; s < SPP; ++s) {
                 int seed = (int)((uint32_t)u.frameIndex * (uint32_t)SPP + (uint32_t)s);
                 Hit h;
-                bool hitAny = traceScene<COUNT>(F, camPos, dir, true, true, h, w);   // the analytic scene (+ the mesh in the hybrid extension)
+                bool hitAny = traceScene<COUNT>(F, camPos, dir, true, true, h, w, true);   // the analytic scene (+ the mesh in the hybrid extension)
                 V3 radiance;
                 if (hitAny) {
                     if (s == 0) {

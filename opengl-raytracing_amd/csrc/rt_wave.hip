@@ -323,6 +323,28 @@ struct DualQueueSrc {
     }
 };
 
+// A dense list of queue addresses (rt_hybrid.hip): ray r is the record at idx[r]; every listed record is a ray.
+struct IndexedSrc {
+    const uint32_t *idx;
+    const uint32_t *count;
+    const float4 *o, *d;
+    float *outT;
+    int *outTri;
+    uint32_t n;
+    RT_DEV void prepare() { n = *count; }
+    RT_DEV uint32_t size() const { return n; }
+    struct Payload { uint32_t a; };
+    RT_DEV float probe(uint32_t r, Payload &p) const { p.a = idx[r]; return 1.0f; }
+    RT_DEV static Payload route(const Payload &p, int e) { Payload q; q.a = (uint32_t)__shfl((int)p.a, e, 64); return q; }
+    RT_DEV void take(uint32_t, const Payload &p, V3 &ro, V3 &rd, uint32_t &token) const {
+        token = p.a;
+        const float4 oo = o[p.a], dd = d[p.a];
+        ro = f4xyz(oo); rd = f4xyz(dd);
+    }
+    RT_DEV void store_closest(uint32_t a, float t, int tri) const { outT[a] = t; outTri[a] = tri; }
+    RT_DEV void store_any(uint32_t, bool) const {}
+};
+
 // hipcc sinks loads into the branches that first use them (e.g. a triangle's v0 behind the determinant test), which turns
 // one gather round trip into two or three dependent ones.  pin() makes a loaded record "used" right after the loads were
 // issued, so the whole group is in flight together.
@@ -1163,6 +1185,17 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
     W_TRY(hipGetLastError());
     return RT_OK;
 }
+
+// Closest-hit traversal of the rays listed in idx[0 .. *count) (queue addresses into o / d; results to outT / outTri at the same address) with the
+// persistent kernel of this pipeline, for rt_hybrid.hip.  `heads`: kHeadWords zeroed cursor words.
+void rt_wave_trace_closest_indexed(hipStream_t st, int cus, int treeDepth, const DevFrame *dFrame, const DevScene &hostScene, const uint32_t *idx,
+                                   const uint32_t *count, const float4 *o, const float4 *d, float *outT, int *outTri, uint32_t *heads) {
+    IndexedSrc q;
+    q.idx = idx; q.count = count; q.o = o; q.d = d; q.outT = outT; q.outTri = outTri; q.n = 0;
+    TraceTune tune{32, 16, 0, 2, 0, 0};
+    launch_trace<IndexedSrc, false>(st, cus, 100, treeDepth, dFrame, hostScene, q, heads, nullptr, nullptr, tune, nullptr);
+}
+size_t rt_wave_head_words() { return kHeadWords; }
 
 int rt_wave_traced(RtWave *w, hipStream_t st, unsigned long long *out8, bool reset) {   // 16 words, see rt_wave.hpp
     for (int i = 0; i < 16; ++i) out8[i] = 0;

@@ -22,6 +22,21 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t stream, const rtd::Dev
 // counted by the diagnostic kernels, RT_TRACE_STATS=1; 0 otherwise)
 int rt_wave_traced(RtWave *w, hipStream_t stream, unsigned long long *out16, bool reset);
 
+// Closest-hit traversal of the rays listed in idx[0 .. *count) (queue addresses into o / d) with the persistent kernel of the wavefront
+// pipeline; results to outT / outTri at the same address.  heads: rt_wave_head_words() zeroed uint32 cursor words.
+void rt_wave_trace_closest_indexed(hipStream_t st, int cus, int treeDepth, const rtd::DevFrame *dFrame, const rtd::DevScene &hostScene, const uint32_t *idx,
+                                   const uint32_t *count, const float4 *o, const float4 *d, float *outT, int *outTri, uint32_t *heads);
+size_t rt_wave_head_words();
+
+// rt_hybrid.hip -- EXTENSION: the hybrid scene (analytic objects + mesh, N diffuse bounces) in stages: shading passes that replay answered mesh
+// queries and queue the open ones, persistent traversal launches in between.  Bit-identical to the megakernel's hybrid frames.
+struct RtHybrid;
+RtHybrid *rt_hybrid_create(int computeUnits);
+void rt_hybrid_destroy(RtHybrid *h);
+const char *rt_hybrid_error(const RtHybrid *h);
+int rt_hybrid_render(RtHybrid *h, RtContext *ctx, hipStream_t stream, const rtd::DevFrame *dFrame, const rtd::DevFrame &host, rtd::Targets tg, int treeDepth,
+                     hipEvent_t evPrevDone);
+
 // stage timing hooks (rt_api.hip); stage ids index rt_stage_name()
 void rt_stage_begin(RtContext *c, int stage, hipStream_t on = nullptr);   // on == nullptr: the context's stream
 void rt_stage_end(RtContext *c, int stage, int launches, hipStream_t on = nullptr);

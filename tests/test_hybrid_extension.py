@@ -65,8 +65,9 @@ def test_oracle_hybrid_mesh_interacts_with_the_analytic_scene(orc):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("pipeline", ["staged", "mega"])
 @pytest.mark.parametrize("bounces,spp,env", [(1, 2, True), (4, 1, True), (2, 3, False)])
-def test_hip_hybrid_frames_match_the_oracle(orc, bounces, spp, env):
+def test_hip_hybrid_frames_match_the_oracle(orc, bounces, spp, env, pipeline):
     W, H = 96, 64
     nodes, tris = _mesh_in_front_of_the_spheres()
     faces = scenes.tiny_env(8) if env else None
@@ -74,7 +75,8 @@ def test_hip_hybrid_frames_match_the_oracle(orc, bounces, spp, env):
     p.sppPerFrame = spp
     p.enableEnvMap = int(env)
     cam = scenes.camera("default", aspect=W / H)
-    with rt.Renderer() as r:
+    # "staged" (RT_PIPELINE_AUTO): replayed shading passes + persistent traversal launches (csrc/rt_hybrid.hip); "mega": one thread per pixel
+    with rt.Renderer(pipeline=rt.RT_PIPELINE_AUTO if pipeline == "staged" else rt.RT_PIPELINE_MEGAKERNEL) as r:
         r.upload_bvh(nodes, tris)
         r.upload_env(faces)
         r.resize(W, H)
@@ -110,3 +112,43 @@ def test_hip_hybrid_with_empty_bvh_is_the_analytic_mode(orc):
             outs.append(r.read_all())
     for a, b in zip(*outs):
         assert np.array_equal(a, b)
+
+
+_STAGED_CODE = r'''
+import sys, numpy as np
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import opengl_raytracing_amd as rt, scenes
+W, H, SPP, BOUNCES = (int(v) for v in sys.argv[1:5])
+v, f = rt.meshgen.bunny_standin(3)
+M = np.eye(4, dtype=np.float32); M[0, 3], M[1, 3], M[2, 3] = -0.1, 1.0, -0.5
+nodes, tris = rt.build_bvh(rt.gather_triangles(v, f, M.T.reshape(-1)))
+faces = scenes.tiny_env(8)
+p = rt.default_render_params(); p.sppPerFrame = SPP
+cam = scenes.camera("default", aspect=W / H)
+outs = {}
+for name, pipe in (("staged", rt.RT_PIPELINE_AUTO), ("mega", rt.RT_PIPELINE_MEGAKERNEL)):
+    with rt.Renderer(pipeline=pipe) as r:
+        r.upload_bvh(nodes, tris); r.upload_env(faces); r.resize(W, H); r.set_extension(gi_bounces=BOUNCES)
+        for frame in range(3):
+            r.render_frame(rt.frame_uniforms(p, cam, W, H, frame, rt.RT_SCENE_HYBRID, nodes.shape[0], tris.shape[0]))
+        outs[name] = r.read_all()
+        if name == "staged":
+            st = r.stage_times() if False else None
+for a, b in zip(outs["staged"], outs["mega"]):
+    assert np.array_equal(a, b)
+print("STAGED-OK")
+'''
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("budget_mb,w,h,spp,bounces", [(8192, 640, 360, 4, 4), (16, 320, 200, 3, 2)])
+def test_staged_hybrid_equals_the_megakernel(budget_mb, w, h, spp, bounces):
+    """The staged hybrid pipeline against the megakernel on a frame that shows everything at once -- mesh, floor, diffuse / glass / mirror
+    spheres, light marker, N bounces, three frames of accumulation -- bit for bit; the second case cuts the frame into many chunks of
+    pixel slots (16 MB of queue + log)."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, RT_QUEUE_BUDGET_MB=str(budget_mb))
+    r = subprocess.run([sys.executable, "-c", _STAGED_CODE, str(w), str(h), str(spp), str(bounces)], cwd=str(scenes.ROOT), env=env, capture_output=True, text=True, timeout=900)
+    assert "STAGED-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
