@@ -965,7 +965,9 @@ constexpr int kMinLaunches = 256;   // trace launches per frame (1 + 3 per chunk
 struct RtWave {
     std::string err;
     int cus = 256;
-    size_t budgetBytes = (size_t)8 << 30;   // ray-queue budget per context; 288 GB of HBM make this cheap
+    // ray-queue budget per frame lane; 288 GB of HBM make this cheap.  16 GB hold the queues of a whole batch of eight 1080p / 4 spp frames (7.4 M hits x
+    // 2.1 KB) in ONE chunk: no hit-count read-back, half the launches (1.76-1.80 -> 1.68-1.72 ms per frame against 8 GB; profiles/r03_experiments.txt)
+    size_t budgetBytes = (size_t)16 << 30;
     TraceTune tune{32, 16, 0, 2, 0, 0};   // chunk 0 = run length chosen in the kernel from the queue size
     // allocations
     size_t slotsCap = 0;      // per-frame arrays sized for this many pixel slots

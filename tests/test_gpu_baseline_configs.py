@@ -251,10 +251,14 @@ def test_batched_frames_fall_back_for_the_analytic_scene_and_the_megakernel(orc)
                 assert np.array_equal(x, y)
 
 
-def test_1080p_batches_of_eight_equal_frame_by_frame_and_the_oracle(orc):
+@pytest.mark.parametrize("budget_mb", [None, 6144])
+def test_1080p_batches_of_eight_equal_frame_by_frame_and_the_oracle(orc, monkeypatch, budget_mb):
     """The mode bench.py times: 1920x1080, 4 spp, 81 920 triangles, rt_render_frames in batches of 8 -- 17 frames = two
-    full batches and a remainder of one, each batch cut into chunks by the ray-queue budget -- against one rt_render_frame per frame: all
-    four targets bit-equal after every batch; and a 64x32 window of the last frame (16 frames of history deep) against the oracle."""
+    full batches and a remainder of one -- against one rt_render_frame per frame: all four targets bit-equal after every batch; and a
+    64x32 window of the last frame (16 frames of history deep) against the oracle.  With the default ray-queue budget a batch is one
+    chunk; with 6 GB it is cut into three (hit count read back, hits dealt over equal chunks)."""
+    if budget_mb:
+        monkeypatch.setenv("RT_QUEUE_BUDGET_MB", str(budget_mb))     # read when the renderer is created
     W, H, FRAMES = 1920, 1080, 17
     nodes, tris = scenes.bunny_bvh(6)
     faces = scenes.env_faces("Sky_01")

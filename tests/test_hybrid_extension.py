@@ -152,3 +152,50 @@ def test_staged_hybrid_equals_the_megakernel(budget_mb, w, h, spp, bounces):
     env = dict(os.environ, RT_QUEUE_BUDGET_MB=str(budget_mb))
     r = subprocess.run([sys.executable, "-c", _STAGED_CODE, str(w), str(h), str(spp), str(bounces)], cwd=str(scenes.ROOT), env=env, capture_output=True, text=True, timeout=900)
     assert "STAGED-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("RT_FUZZ_CASES", "8"))))
+def test_random_hybrid_scenes_match_the_oracle_on_both_pipelines(orc, seed):
+    """Randomised sweep of the hybrid extension: random mesh placement among the analytic objects (in front of, beside, inside the glass /
+    mirror spheres' neighbourhood), cameras, toggles, materials, 1-4 bounces, 1-3 spp, ragged frame sizes, moving and static cameras;
+    the staged pipeline and the megakernel must both equal the own oracle bit for bit on three consecutive frames."""
+    rng = np.random.default_rng(9000 + seed)
+    v, f = rt.meshgen.bunny_standin(int(rng.integers(0, 3)), seed=int(rng.integers(1 << 30)))
+    M = np.eye(4, dtype=np.float32)
+    M[0, 0] = M[1, 1] = M[2, 2] = float(rng.uniform(0.3, 1.2))
+    M[0, 3], M[1, 3], M[2, 3] = float(rng.uniform(-1.5, 1.5)), float(rng.uniform(0.4, 1.6)), float(rng.uniform(-4.5, 1.0))
+    nodes, tris = rt.build_bvh(rt.gather_triangles(v, f, M.T.reshape(-1)))
+    W, H = int(rng.integers(17, 90)), int(rng.integers(17, 64))
+    p = rt.default_render_params()
+    p.sppPerFrame = int(rng.choice([1, 2, 3]))
+    for name in ("enableGI", "enableAO", "enableTAA", "enableJitter", "sunEnabled", "skyEnabled", "pointLightEnabled", "enableEnvMap",
+                 "matGlassEnabled", "matMirrorEnabled"):
+        setattr(p, name, int(rng.random() < 0.8))
+    p.aoSamples = int(rng.integers(1, 6))
+    p.pointLightPos[0], p.pointLightPos[1], p.pointLightPos[2] = float(rng.normal(0, 1.5)), float(rng.uniform(0.5, 4.0)), float(rng.uniform(-5, 1))
+    bounces = int(rng.integers(1, 5))
+    moving = bool(rng.random() < 0.4)
+    cams = []
+    for k in range(3):
+        c = scenes.camera("default", aspect=W / H)
+        c.pos[0] += float(rng.normal(0, 0.6)); c.pos[1] += float(rng.normal(0, 0.4)); c.pos[2] += float(rng.normal(0, 1.0))
+        c.yaw += float(rng.normal(0, 8)); c.pitch += float(rng.normal(0, 6)); c.fov = float(rng.uniform(35, 80))
+        cams.append(c)
+    faces = scenes.tiny_env(int(rng.choice([1, 4, 8])), seed=int(rng.integers(100))) if p.enableEnvMap else None
+    for pipeline in (rt.RT_PIPELINE_AUTO, rt.RT_PIPELINE_MEGAKERNEL):
+        with rt.Renderer(pipeline=pipeline) as r:
+            r.upload_bvh(nodes, tris)
+            r.upload_env(faces)
+            r.resize(W, H)
+            r.set_extension(gi_bounces=bounces)
+            prev, prev_vp = None, None
+            for frame in range(3):
+                cam = cams[frame] if moving else cams[0]
+                u = rt.frame_uniforms(p, cam, W, H, frame, rt.RT_SCENE_HYBRID, nodes.shape[0], tris.shape[0], prev_vp=prev_vp, env_loaded=faces is not None)
+                prev_vp = rt.mat4_mul(rt.camera_proj(cam), rt.camera_view(cam))
+                r.render_frame(u)
+                want, _ = orc.render(u, nodes, tris, faces, prev, gi_bounces=bounces)
+                for g, w_, name in zip(r.read_all(), want, ("color", "motion", "gpos", "gnrm")):
+                    assert np.array_equal(g, w_), (seed, pipeline, frame, name, int(np.sum(g != w_)))
+                prev = want[0]
