@@ -47,6 +47,7 @@ struct RtContext {
     int envSize = 0;
     int nNodes = 0, nTris = 0, nInner = 0, rootRef = 0, rootRef4 = 0, treeDepth = 0;
     size_t nWide4 = 0, nPairs = 0;   // records in dW4 / dPairs
+    int anyStack = 0;                // stack entries of the any-hit walk (0: from the binary depth)
     float rootMin[3] = {0, 0, 0}, rootMax[3] = {0, 0, 0};
     // frame state
     FrameGeom g{};
@@ -217,6 +218,7 @@ DevScene make_dev_scene(const RtContext *c) {
     s.rootRef = c->rootRef;
     s.rootRef4 = c->rootRef4;
     s.hasBVH = (c->nNodes > 0 && c->nTris > 0) ? 1 : 0;
+    s.anyStack = c->anyStack;
     std::memcpy(s.rootMin, c->rootMin, 12);
     std::memcpy(s.rootMax, c->rootMax, 12);
     return s;
@@ -391,6 +393,7 @@ int rt_upload_bvh(RtContext *c, const float *nodes12, int nNodes, const float *t
     c->nNodes = c->nTris = c->nInner = 0;
     c->treeDepth = 0;
     c->nWide4 = c->nPairs = 0;
+    c->anyStack = 0;
     if (nNodes == 0 || nTris == 0) return RT_OK;
     if (nTris >= (1 << 28)) return fail(c, RT_ERR_UNSUPPORTED, "rt_upload_bvh: %d triangles exceed the 2^28 leaf encoding", nTris);
 
@@ -521,11 +524,132 @@ int rt_upload_bvh(RtContext *c, const float *nodes12, int nNodes, const float *t
             }
         }
     } else w4.resize(32, 0.0f);
+    // EXPERIMENT (RT_ANYHIT_TREE=sah): any-hit answers do not depend on the tree, only on which reference leaves pass their own
+    // exact box test -- so the 4-wide tree may be ANY tree over the reference's leaves whose inner boxes contain their leaves' boxes.  Binned SAH
+    // (16 bins, cost = area x triangles) over the leaves, collapsed to four children by pulling up the child of largest area.  Off by default: it
+    // needs more node visits than the collapse of the balanced median-split tree on the bench mesh.
+    int anyStack = 0;
+    if (const char *e = getenv("RT_ANYHIT_TREE")) if (std::string(e) == "sah" && nd[0].count <= 0) {
+        struct Leaf { float lo[3], hi[3], cen[3]; int ref; float w; };
+        std::vector<Leaf> leaves;
+        for (int i = 0; i < nNodes; ++i) if (nd[(size_t)i].count > 0) {
+            Leaf L;
+            const float *b = nodes12 + (size_t)i * 12;
+            for (int a = 0; a < 3; ++a) { L.lo[a] = b[a]; L.hi[a] = b[4 + a]; L.cen[a] = 0.5f * (b[a] + b[4 + a]); }
+            L.ref = refOfW(i); L.w = (float)nd[(size_t)i].count;
+            leaves.push_back(L);
+        }
+        struct BNode { float lo[3], hi[3]; int left, right, leaf; };
+        std::vector<BNode> B;
+        std::vector<int> ids(leaves.size());
+        for (size_t i = 0; i < ids.size(); ++i) ids[i] = (int)i;
+        auto area = [](const float *lo, const float *hi) { float ex = std::max(hi[0] - lo[0], 0.0f), ey = std::max(hi[1] - lo[1], 0.0f), ez = std::max(hi[2] - lo[2], 0.0f); return 2.0f * (ex * ey + ey * ez + ez * ex); };
+        struct Job { int begin, end, node, depth; };
+        std::vector<Job> todo;
+        B.push_back(BNode{});
+        todo.push_back({0, (int)ids.size(), 0, 0});
+        constexpr int NB = 16;
+        while (!todo.empty()) {
+            const Job jb = todo.back();
+            todo.pop_back();
+            BNode bn{};
+            for (int a = 0; a < 3; ++a) { bn.lo[a] = 3.0e38f; bn.hi[a] = -3.0e38f; }
+            float clo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, chi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+            for (int i = jb.begin; i < jb.end; ++i) {
+                const Leaf &L = leaves[(size_t)ids[(size_t)i]];
+                for (int a = 0; a < 3; ++a) { bn.lo[a] = std::min(bn.lo[a], L.lo[a]); bn.hi[a] = std::max(bn.hi[a], L.hi[a]); clo[a] = std::min(clo[a], L.cen[a]); chi[a] = std::max(chi[a], L.cen[a]); }
+            }
+            bn.left = bn.right = -1; bn.leaf = -1;
+            if (jb.end - jb.begin == 1) { bn.leaf = ids[(size_t)jb.begin]; B[(size_t)jb.node] = bn; continue; }
+            int bestAxis = -1, bestSplit = -1;
+            float bestCost = 3.0e38f;
+            for (int a = 0; a < 3 && jb.depth < 40; ++a) {
+                const float ext = chi[a] - clo[a];
+                if (!(ext > 0.0f)) continue;
+                float blo[NB][3], bhi[NB][3], bw[NB];
+                for (int k = 0; k < NB; ++k) { bw[k] = 0.0f; for (int q = 0; q < 3; ++q) { blo[k][q] = 3.0e38f; bhi[k][q] = -3.0e38f; } }
+                for (int i = jb.begin; i < jb.end; ++i) {
+                    const Leaf &L = leaves[(size_t)ids[(size_t)i]];
+                    const int k = std::min(NB - 1, (int)((L.cen[a] - clo[a]) / ext * NB));
+                    bw[k] += L.w;
+                    for (int q = 0; q < 3; ++q) { blo[k][q] = std::min(blo[k][q], L.lo[q]); bhi[k][q] = std::max(bhi[k][q], L.hi[q]); }
+                }
+                float rlo[NB][3], rhi[NB][3], rw[NB];
+                float alo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, ahi[3] = {-3.0e38f, -3.0e38f, -3.0e38f}, aw = 0.0f;
+                for (int k = NB - 1; k >= 0; --k) {
+                    aw += bw[k];
+                    for (int q = 0; q < 3; ++q) { alo[q] = std::min(alo[q], blo[k][q]); ahi[q] = std::max(ahi[q], bhi[k][q]); rlo[k][q] = alo[q]; rhi[k][q] = ahi[q]; }
+                    rw[k] = aw;
+                }
+                float llo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, lhi[3] = {-3.0e38f, -3.0e38f, -3.0e38f}, lw = 0.0f;
+                for (int k = 0; k + 1 < NB; ++k) {
+                    lw += bw[k];
+                    for (int q = 0; q < 3; ++q) { llo[q] = std::min(llo[q], blo[k][q]); lhi[q] = std::max(lhi[q], bhi[k][q]); }
+                    if (lw == 0.0f || rw[k + 1] == 0.0f) continue;
+                    const float cost = area(llo, lhi) * lw + area(rlo[k + 1], rhi[k + 1]) * rw[k + 1];
+                    if (cost < bestCost) { bestCost = cost; bestAxis = a; bestSplit = k; }
+                }
+            }
+            int mid;
+            if (bestAxis < 0) {   // degenerate centroids or the depth cap: median by index
+                mid = (jb.begin + jb.end) / 2;
+            } else {
+                const float ext = chi[bestAxis] - clo[bestAxis];
+                auto it = std::partition(ids.begin() + jb.begin, ids.begin() + jb.end, [&](int id) {
+                    return std::min(NB - 1, (int)((leaves[(size_t)id].cen[bestAxis] - clo[bestAxis]) / ext * NB)) <= bestSplit; });
+                mid = (int)(it - ids.begin());
+                if (mid == jb.begin || mid == jb.end) mid = (jb.begin + jb.end) / 2;
+            }
+            bn.left = (int)B.size(); B.push_back(BNode{});
+            bn.right = (int)B.size(); B.push_back(BNode{});
+            B[(size_t)jb.node] = bn;
+            todo.push_back({jb.begin, mid, bn.left, jb.depth + 1});
+            todo.push_back({mid, jb.end, bn.right, jb.depth + 1});
+        }
+        // collapse to four children
+        std::vector<float> s4(32, 0.0f);
+        struct J4 { int bin; size_t at; int depth; };
+        std::vector<J4> jobs4{{0, 0, 1}};
+        int depth4 = 1;
+        while (!jobs4.empty()) {
+            const J4 jb = jobs4.back();
+            jobs4.pop_back();
+            depth4 = std::max(depth4, jb.depth);
+            std::vector<int> kids{B[(size_t)jb.bin].left, B[(size_t)jb.bin].right};
+            while (kids.size() < 4) {
+                int pick = -1;
+                float best = -1.0f;
+                for (size_t i = 0; i < kids.size(); ++i) if (B[(size_t)kids[i]].leaf < 0) { const float ar = area(B[(size_t)kids[i]].lo, B[(size_t)kids[i]].hi); if (ar > best) { best = ar; pick = (int)i; } }
+                if (pick < 0) break;
+                const int k = kids[(size_t)pick];
+                kids.erase(kids.begin() + pick);
+                kids.push_back(B[(size_t)k].left); kids.push_back(B[(size_t)k].right);
+            }
+            for (int i = 0; i < 4; ++i) {
+                int ref = RT_NO_CHILD;
+                float *o = &s4[jb.at * 32];
+                if (i < (int)kids.size()) {
+                    const BNode &kb = B[(size_t)kids[(size_t)i]];
+                    if (kb.leaf >= 0) ref = leaves[(size_t)kb.leaf].ref;
+                    else { ref = (int)(s4.size() / 32); s4.resize(s4.size() + 32, 0.0f); jobs4.push_back({kids[(size_t)i], (size_t)ref, jb.depth + 1}); o = &s4[jb.at * 32]; }
+                    // a leaf child carries the reference's exact leaf box (the test that decides which triangles are tested); an inner child the union of its leaves' boxes
+                    const float *lo = kb.leaf >= 0 ? leaves[(size_t)kb.leaf].lo : kb.lo, *hi = kb.leaf >= 0 ? leaves[(size_t)kb.leaf].hi : kb.hi;
+                    o[0 + i] = lo[0]; o[4 + i] = lo[1]; o[8 + i] = lo[2]; o[12 + i] = hi[0]; o[16 + i] = hi[1]; o[20 + i] = hi[2];
+                } else {
+                    const float qnan = std::nanf("");
+                    o[0 + i] = o[4 + i] = o[8 + i] = o[12 + i] = o[16 + i] = o[20 + i] = qnan;
+                }
+                std::memcpy(&s4[jb.at * 32 + 24 + (size_t)i], &ref, 4);
+            }
+        }
+        if (3 * depth4 <= 60) { w4.swap(s4); rootRef4 = 0; anyStack = 3 * depth4; }
+    }
     if (depth > 32) return fail(c, RT_ERR_UNSUPPORTED, "rt_upload_bvh: tree depth %d exceeds the 32-entry traversal stack", depth);
     HIP_TRY(c, hipMalloc(&c->dWNodes, wn.size() * sizeof(float)));
     HIP_TRY(c, hipMalloc(&c->dW4, w4.size() * sizeof(float)));
     HIP_TRY(c, hipMemcpy(c->dW4, w4.data(), w4.size() * sizeof(float), hipMemcpyHostToDevice));
     c->rootRef4 = rootRef4;
+    c->anyStack = anyStack;
     c->rootRefW = refOfW(0);
     HIP_TRY(c, hipMalloc(&c->dWNodesW, wnW.size() * sizeof(float)));
     HIP_TRY(c, hipMemcpy(c->dWNodesW, wnW.data(), wnW.size() * sizeof(float), hipMemcpyHostToDevice));

@@ -39,6 +39,7 @@ struct DevScene {
     int rootRefW;
     int hasBVH;
     float rootMin[3], rootMax[3];
+    int anyStack;   // per-lane stack entries the any-hit walk of w4 can need (3 per level of the 4-wide tree)
 };
 
 struct Work {   // RtCounters, per lane

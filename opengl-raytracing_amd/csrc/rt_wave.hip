@@ -940,7 +940,7 @@ void launch_trace(hipStream_t st, int cus, int gridPct, int depth, const DevFram
     // Stack entries: closest-hit defers one sibling per binary level (8 B each); any-hit walks 4-wide nodes and can
     // defer three per two levels (4 B each).  Resident 256-thread workgroups per CU follow from the LDS footprint and the kernel's
     // registers: asked from the runtime per (kernel, stack size), the persistent grid is exactly what fits.
-    const int stack = std::max(4, ANY ? 3 * ((depth + 1) / 2) : depth);
+    const int stack = std::max(4, ANY ? (hs.anyStack > 0 ? hs.anyStack : 3 * ((depth + 1) / 2)) : depth);
     const size_t ldsBytes = (size_t)256 * stack * (ANY ? 4 : 8);
     const float4 *nodes = ANY ? hs.w4 : hs.wnodesW;
     auto go = [&](auto kernel) {
