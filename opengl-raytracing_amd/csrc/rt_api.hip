@@ -33,6 +33,7 @@ struct RtContext {
     // up to nLanes consecutive frames overlap everywhere except at the temporal resolve.  stream == lanes[0]: every
     // non-frame operation runs there after a sync of all lanes.
     int nLanes = 3;
+    bool serialFrames = false;          // RT_LANES=1: a frame starts when its predecessor has finished
     hipStream_t lanes[RT_MAX_LANES] = {};
     hipStream_t stream = nullptr;
     hipStream_t lastStream = nullptr;    // stream of the most recent frame (gather / assemble are ordered behind it)
@@ -338,6 +339,10 @@ int rt_create(const RtDeviceConfig *cfg, RtContext **out) {
     // round 3, batches of eight frames with 75 % persistent grids: 1.76 / 1.75 ms per frame with 3 / 4 lanes
     c->nLanes = 4;
     if (const char *e = getenv("RT_LANES")) c->nLanes = std::max(1, std::min(RT_MAX_LANES, atoi(e)));
+    // RT_LANES=1 = one frame (launch set) in flight.  The COLOR0 ring still needs two buffers -- with one, a moving frame's reprojection would read
+    // history texels its own resolve is overwriting (rt_taa.glsl:128 reads the previous frame at arbitrary pixels) -- so it is two lanes whose
+    // frames wait for their predecessor from the first kernel on.
+    if (c->nLanes == 1) { c->nLanes = 2; c->serialFrames = true; }
     bool ok = hipMalloc(&c->dCounters, 16 * sizeof(unsigned long long)) == hipSuccess;
     for (int i = 0; ok && i < c->nLanes; ++i)
         ok = hipStreamCreateWithFlags(&c->lanes[i], hipStreamNonBlocking) == hipSuccess && hipMalloc(&c->dFrame[i], sizeof(DevFrame)) == hipSuccess &&
@@ -783,6 +788,7 @@ static int render_frames_impl(RtContext *c, const RtUniforms *uIn, int batch, co
     // reader of a COLOR0 buffer (gather, assemble) is stream-ordered before the next writer of the same buffer.
     const int lane = c->writeIdx, prevLane = (c->writeIdx + c->nLanes - 1) % c->nLanes;
     hipStream_t st = c->lanes[lane];
+    if (c->serialFrames) HIP_TRY(c, hipStreamWaitEvent(st, c->evDone[prevLane], 0));
     HIP_TRY(c, hipMemcpyAsync(c->dFrame[lane], &fr, sizeof(fr), hipMemcpyHostToDevice, st));
     Targets tg;
     tg.color = c->dColor[c->writeIdx];

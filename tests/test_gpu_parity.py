@@ -315,14 +315,19 @@ print("CHUNKED-OK")
     assert "CHUNKED-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
+@pytest.mark.parametrize("lanes", [None, 1])
 @pytest.mark.parametrize("pipeline", ["mega", "wave"])
 @pytest.mark.parametrize("use_bvh", [False, True])
-def test_moving_camera_reprojection(orc, pipeline, use_bvh):
+def test_moving_camera_reprojection(orc, monkeypatch, pipeline, use_bvh, lanes):
     """Camera path: rt_render_ray keeps FrameState (prev/curr view-projection), raises cameraMoved, switches the
     jitter scale (application.cpp:387-405); the shader writes motion vectors and resolveTAA takes the reprojection
-    branch (rt_taa.glsl:116-179), with the (4,4) disocclusion marker on misses (rt.frag:172-175)."""
+    branch (rt_taa.glsl:116-179), with the (4,4) disocclusion marker on misses (rt.frag:172-175).
+    lanes=1 (RT_LANES=1, one frame in flight): the history the reprojection reads must still be a buffer of its own -- with a
+    COLOR0 ring of one a moving frame read texels its own resolve was overwriting (found in round 3)."""
     if pipeline == "wave" and not use_bvh:
         pytest.skip("the analytic scene always runs in the megakernel")
+    if lanes:
+        monkeypatch.setenv("RT_LANES", str(lanes))
     W, H = 160, 96
     nodes, tris = scenes.bunny_bvh(3)
     faces = scenes.tiny_env(8)
