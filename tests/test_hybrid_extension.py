@@ -199,3 +199,29 @@ def test_random_hybrid_scenes_match_the_oracle_on_both_pipelines(orc, seed):
                 for g, w_, name in zip(r.read_all(), want, ("color", "motion", "gpos", "gnrm")):
                     assert np.array_equal(g, w_), (seed, pipeline, frame, name, int(np.sum(g != w_)))
                 prev = want[0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,rank", [(3, 1), (8, 7)])
+def test_staged_hybrid_on_a_tile_parallel_rank_equals_the_megakernel(world, rank):
+    """One rank of a tile-parallel frame (16x16 tiles with tile % world == rank) renders the hybrid extension in stages: the same tiles as the
+    megakernel, bit for bit, over three frames of accumulation."""
+    W, H = 200, 120
+    nodes, tris = _mesh_in_front_of_the_spheres()
+    faces = scenes.tiny_env(8)
+    p = rt.default_render_params()
+    p.sppPerFrame = 2
+    cam = scenes.camera("default", aspect=W / H)
+    outs = []
+    for pipe in (rt.RT_PIPELINE_AUTO, rt.RT_PIPELINE_MEGAKERNEL):
+        with rt.Renderer(rank=rank, world_size=world, pipeline=pipe) as r:
+            r.upload_bvh(nodes, tris)
+            r.upload_env(faces)
+            r.resize(W, H)
+            r.set_extension(gi_bounces=2)
+            for frame in range(3):
+                r.render_frame(rt.frame_uniforms(p, cam, W, H, frame, rt.RT_SCENE_HYBRID, nodes.shape[0], tris.shape[0]))
+            outs.append(r.read_all())
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+    assert outs[0][0].any()
