@@ -81,7 +81,8 @@ __device__ __noinline__ bool traceAnalyticCore(const RtUniforms &u, V3 ro, V3 rd
 // config 3 "run B"): the BVH mesh is one more object at the end of the list, under the list's own rule (strict <: an earlier object
 // wins a tie); its hit is what traceBVH returns (geometric normal), its material id MAT_MESH.
 // `geometric`: the caller builds later rays from this hit (primary, bounce, reflection, refraction); false for visibility / AO queries,
-// whose answers only scale radiance.  Only the staged pipeline looks at it.
+// whose answers only scale radiance.  The staged pipeline speculates "miss" for every open query alike; when a speculation fails, the
+// answers recorded behind a failed GEOMETRIC query are void (their rays were built from the wrong hit), those behind a visibility query are not.
 template <bool COUNT>
 __device__ __noinline__ bool traceScene(const Frag &F, V3 ro, V3 rd, bool includeGlass, bool includeMarker, Hit &hit, Work &w, bool geometric = false) {
     const RtUniforms &u = *F.u;
@@ -107,16 +108,15 @@ __device__ __noinline__ bool traceScene(const Frag &F, V3 ro, V3 rd, bool includ
                     any = true;
                 }
             } else {
+                // open: recorded, and answered "no mesh hit" -- a speculation the next pass checks against the traced answer (rt_hybrid.hip).  Everything
+                // the thread does after it is right exactly if that answer, and every later speculated one, turns out to be a miss.
                 R.pending++;
-                if (!R.poisoned) {
-                    if (q < R.qmax) {
-                        const size_t a = (size_t)q * R.stride + R.thread;
-                        R.o[a] = make_float4(ro.x, ro.y, ro.z, 0.0f);
-                        R.d[a] = make_float4(rd.x, rd.y, rd.z, 0.0f);
-                        R.recEnd = q + 1u;
-                    } else R.overflow = true;
-                    if (geometric) R.poisoned = true;
-                }
+                if (q < R.qmax) {
+                    const size_t a = (size_t)q * R.stride + R.thread;
+                    R.o[a] = make_float4(ro.x, ro.y, ro.z, hit.t);   // .w: the analytic scene's hit distance (uINF: none) -- a mesh hit behind it changes nothing
+                    R.d[a] = make_float4(rd.x, rd.y, rd.z, geometric ? 1.0f : 0.0f);   // .w: later rays are built from this hit
+                    R.recEnd = q + 1u;
+                } else R.overflow = true;
             }
         }
         return any;

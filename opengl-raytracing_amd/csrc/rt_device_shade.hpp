@@ -272,8 +272,7 @@ struct Replay {
     uint32_t q = 0;           // queries met so far in this pass
     uint32_t known = 0;       // queries answered by earlier passes
     uint32_t recEnd = 0;      // one past the last query recorded in this pass
-    uint32_t pending = 0;     // queries without an answer met in this pass (recorded or not)
-    bool poisoned = false;    // an unanswered query that later geometry depends on was met: what follows it is not recorded
+    uint32_t pending = 0;     // queries without an answer met in this pass: recorded, and answered "no hit" on speculation
     bool overflow = false;    // more than qmax queries
     uint32_t thread = 0, stride = 0, qmax = 0;
     float4 *o = nullptr, *d = nullptr;

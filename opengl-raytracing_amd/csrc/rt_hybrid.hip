@@ -6,13 +6,18 @@
 // secondary rays, each shaded with six visibility queries; mirror; N bounces), so it is not cut into stages by hand.  Instead it is
 // REPLAYED: thread = (pixel, sample) runs the unchanged shading code with a Replay state (rt_device_shade.hpp) behind the one function
 // all mesh queries go through (traceScene).  Queries are numbered in program order; a query answered by an earlier pass is read from
-// the thread's log, an open one is written to the thread's slot of a ray queue (and answered "no mesh hit" for now); once an open query
-// is one that later rays depend on ("geometric": primary, bounce, reflection, refraction), nothing after it is recorded.  At the end of a
+// the thread's log, an open one is written to the thread's slot of a ray queue and answered "no mesh hit" ON SPECULATION: the thread goes on
+// -- recording every later query too -- as if that were the answer, and keeps the radiance it arrives at.  The next pass first checks the
+// traced answers of what the thread recorded: if none of them is a mesh hit in front of the analytic scene's own hit, everything the thread
+// did was right and it is finished without being shaded again (with the reference's default camera the mesh stands between the floor and the
+// point light: nearly every sample has such a query, and about half of them miss the mesh); otherwise the answers up to the first such
+// hit of a query that later rays were built from (primary, bounce, reflection, refraction -- visibility hits leave the later queries valid) join the
+// log and the thread is shaded again from there.  At the end of a
 // pass every wave appends the queue addresses of what its threads recorded to a dense list (one atomic per wave; query-major inside the
 // wave's block, so that neighbouring list entries are the same kind of ray of neighbouring pixels), and between two shading passes ONE
-// persistent closest-hit launch of the wavefront pipeline (k_trace over that list, rt_wave.hip) traces everything recorded.  A thread
-// whose pass met no open query is finished; its radiance is final and bit-identical to the megakernel's, because every operation it executed saw the same inputs.  Passes per frame = longest chain of dependent mesh queries + 2
-// (diffuse pixel with N bounces: N + 3).  Rays that miss the mesh's root box never enter the queue (the test bvh_closest starts with).
+// persistent closest-hit launch of the wavefront pipeline (k_trace over that list, rt_wave.hip) traces everything recorded.  A finished
+// thread's radiance is bit-identical to the megakernel's, because every operation it executed saw the same inputs.  Passes per chunk = the
+// longest chain of mesh HITS a sample's rays depend on + 2.  Rays that miss the mesh's root box never enter the queue (the test bvh_closest starts with).
 #include <algorithm>
 #include <cstdio>
 #include <string>
@@ -35,7 +40,7 @@ struct HybridBuf {
     uint32_t *idx;         //            dense list of the queue addresses recorded in this pass (cnt[1] entries)
     float *logT;           //            answers: t (inf on a miss) ...
     int *logTri;           //            ... and triangle (-1 on a miss)
-    uint32_t *state;       // [T] number of answered queries, or kDone
+    uint32_t *state;       // [T] answered queries | recorded-up-to << 16, or kDone
     float4 *rad;           // [T] final radiance of (pixel, sample)
     float2 *sMotion;       // [nS] from the sample-0 thread: rt.frag:94-101, 172-175
     float4 *sPos, *sNrm;   // [nS]
@@ -62,8 +67,27 @@ __global__ __launch_bounds__(256, 5) void k_hybrid_shade(const DevFrame *__restr
                 hb.rad[tid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // padding of a ragged tile: nothing to render
                 hb.state[tid] = kDone;
             } else {
+                // check last pass's speculation: queries [known, rec) were recorded and answered "no mesh hit" on the spot
+                uint32_t kn = st & 0xffffu;
+                const uint32_t rec = st >> 16;
+                bool finished = false;
+                if (rec > kn) {
+                    bool anyHit = false;
+                    uint32_t valid = rec;                  // answers [kn, valid) are answers to the queries the true frame asks
+                    for (uint32_t q = kn; q < rec; ++q) {
+                        const size_t a = (size_t)q * hb.T + tid;
+                        if (hb.logTri[a] >= 0 && hb.logT[a] < hb.o[a].w) {       // a mesh hit in front of the analytic scene's: the speculation failed here
+                            anyHit = true;
+                            if (hb.d[a].w != 0.0f) { valid = q + 1u; break; }      // later rays were built from the wrong hit: what follows is void
+                        }
+                    }
+                    if (!anyHit) finished = true;          // every speculated miss was one: the stored radiance is final
+                    else kn = valid;                       // shade again with these answers known
+                }
+                if (finished) { hb.state[tid] = kDone; }
+                else {
                 Replay R;
-                R.known = st;
+                R.known = kn;
                 R.thread = tid; R.stride = hb.T; R.qmax = hb.qmax;
                 R.o = hb.o; R.d = hb.d; R.logT = hb.logT; R.logTri = hb.logTri;
                 Frag F;
@@ -95,19 +119,22 @@ __global__ __launch_bounds__(256, 5) void k_hybrid_shade(const DevFrame *__restr
                     if (u.cameraMoved == 1 && s == 0) motion = mk2(4.0f, 4.0f);
                 }
                 if (R.overflow) atomicOr(&hb.cnt[2], 1u);
+                // the result of this pass is kept either way: final if nothing was open, else provisional until the next pass has checked the speculation
+                hb.rad[tid] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
+                if (s == 0) {
+                    hb.sMotion[i] = make_float2(motion.x, motion.y);
+                    hb.sPos[i] = make_float4(gpos.x, gpos.y, gpos.z, gpos.w);
+                    hb.sNrm[i] = make_float4(gnrm.x, gnrm.y, gnrm.z, gnrm.w);
+                }
                 if (R.pending == 0u) {
-                    hb.rad[tid] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
-                    if (s == 0) {
-                        hb.sMotion[i] = make_float2(motion.x, motion.y);
-                        hb.sPos[i] = make_float4(gpos.x, gpos.y, gpos.z, gpos.w);
-                        hb.sNrm[i] = make_float4(gnrm.x, gnrm.y, gnrm.z, gnrm.w);
-                    }
                     hb.state[tid] = kDone;
                 } else {
                     open = true;
                     known = R.known;
-                    recorded = R.recEnd > R.known ? R.recEnd - R.known : 0u;   // queries [known, recEnd) were recorded: answered after the next launch
-                    hb.state[tid] = max(R.recEnd, R.known);
+                    const uint32_t recEnd = max(R.recEnd, R.known);
+                    recorded = recEnd - R.known;   // queries [known, recEnd) were recorded: traced by the next launch
+                    hb.state[tid] = R.known | (recEnd << 16);
+                }
                 }
             }
         }
@@ -219,6 +246,7 @@ int rt_hybrid_render(RtHybrid *h, RtContext *ctx, hipStream_t st, const DevFrame
     size_t nS = std::min(nSlots, std::max<size_t>(h->budgetBytes / perSlot, 256));
     nS = std::max<size_t>(nS / 256 * 256, 256);
     const size_t Tmax = nS * (size_t)SPP;
+    if (qmax > 0xfff0u) { h->err = "hybrid: query log too long"; return RT_ERR_UNSUPPORTED; }
     if (Tmax * qmax >= ((size_t)1 << 31)) {   // queue addresses are 31-bit in the traversal kernel
         nS = std::max<size_t>((((size_t)1 << 31) - 1) / ((size_t)qmax * SPP) / 256 * 256, 256);
     }
