@@ -93,6 +93,9 @@ def parse_args(argv=None):
     ap.add_argument("--force-gather", action="store_true", help="rehearsal on one GPU: run the N > 1 code path (process group, communicator, "
                     "gather per batch) with a world of one (self-launched like N > 1 unless an outer launcher set WORLD_SIZE)")
     ap.add_argument("--gather", default="native", choices=["native", "torch"], help="N > 1: the library's own RCCL communicator (C ABI) or torch.distributed")
+    ap.add_argument("--rehearse-one-gpu", action="store_true", help="N > 1 ranks as N processes that all render on GPU 0, with a gloo process group and "
+                    "host-staged gathers (RCCL refuses two ranks on one device): the multi-process code path on a one-GPU box.  Rank 0 also renders the "
+                    "frame alone and compares it with the assembled one (config.assembled_equals_single_rank).  Not a measurement")
     ap.add_argument("--launch", action="store_true", help="start the rank(s) through the self-launcher even for --gpus 1 (rehearsal of the N > 1 start-up "
                     "on a one-GPU box, together with --force-gather)")
     ap.add_argument("--dry-launch", action="store_true", help="--gpus N > 1 without WORLD_SIZE: print the child command / environment as JSON and exit")
@@ -183,12 +186,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     args.gpus = world
+    if args.rehearse_one_gpu:
+        local_rank = 0                 # every rank on GPU 0
+        args.gather = "torch"          # the library's own communicator is RCCL
     torch.cuda.set_device(local_rank)
     multi = world > 1 or args.force_gather      # the tile-parallel code path (process group, communicator, gathers)
     if multi:
         import faulthandler
         faulthandler.dump_traceback_later(args.rank_timeout, exit=True)   # per-rank watchdog: a rank stuck in a collective ends itself
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     pipeline = {"auto": rt.RT_PIPELINE_AUTO, "mega": rt.RT_PIPELINE_MEGAKERNEL, "wave": rt.RT_PIPELINE_WAVEFRONT}[args.pipeline]
     mesh_desc = None
@@ -261,7 +270,8 @@ def main():
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if args.gather != "native" or ok.item() == 0:
                 gatherer = FrameGatherer(ren, gather_every=args.gather_every)
-                gather_path["path"] = "torch.distributed (RCCL) on the library's device pointers"
+                gather_path["path"] = ("torch.distributed (gloo, blocks staged through host memory): REHEARSAL, every rank on GPU 0" if args.rehearse_one_gpu
+                                       else "torch.distributed (RCCL) on the library's device pointers")
         # setup, not a step: every frame lane (3-4 streams with their own ray-queue arenas) allocates on its first frame; do that
         # before the W warm-up steps so that a small W cannot push a multi-GB hipMalloc into the timed region
         setup_u = [uniforms(cam, f) for f in range(5 * B)]
@@ -311,6 +321,23 @@ def main():
         traced = ren.traced_rays()
         info = ren.scene_info()
         batched_hash = color_hash(ren) if check else None
+        assembled_same = None
+        if args.rehearse_one_gpu and gatherer is not None and world > 1:
+            # rank 0: the frame the ranks' tiles were assembled into == the same frames rendered by one context that owns every tile
+            asm = gatherer.frame_halfs() if rank == 0 else None
+            if rank == 0:
+                solo = rt.Renderer(device=local_rank, rank=0, world_size=1, pipeline=pipeline)
+                solo.upload_bvh(nodes, tris)
+                solo.upload_env(faces)
+                solo.resize(W, H)
+                if args.gi_bounces != 1:
+                    solo.set_extension(gi_bounces=args.gi_bounces)
+                for f in range(0, warmup + steps, B):
+                    solo.render_frames(frames_u[f:min(f + B, warmup + steps)])
+                solo.synchronize()
+                ref = np.ascontiguousarray(solo.read_target(rt.RT_TARGET_COLOR)).view("<u2").reshape(asm.shape)
+                solo.close()
+                assembled_same = bool(np.array_equal(ref, asm))
         ren.close()
 
         # Self-check + comparison figure: the same frame indices, one rt_render_frame per frame (three frames in flight).  Frames
@@ -344,7 +371,8 @@ def main():
         traced_per_frame = int(tr[0].item()) // frames_all if traced.frames else 0
         return {"seconds": float(tt.item()), "counters": total, "local_counters": cnt, "stages": stages,
                 "traced_per_frame": traced_per_frame, "traced": traced, "scene_info": info, "counted_frames": steps,
-                "batched_hash": batched_hash, "fbf_hash": fbf_hash, "fbf_ms": fbf_ms, "same": bool(same.item()) if check else None}
+                "batched_hash": batched_hash, "fbf_hash": fbf_hash, "fbf_ms": fbf_ms, "same": bool(same.item()) if check else None,
+                "assembled_same": assembled_same}
 
     if args.hybrid:
         # the mesh stands among the analytic objects, seen from the reference's default camera (include/app/state.h:129-131)
@@ -516,6 +544,7 @@ def main():
                    "batching": "rt_render_frames: consecutive frames of the static camera (they differ in uFrameIndex and uJitter only) share one set of "
                                "kernel launches; every frame is fully rendered",
                    "batched_equals_frame_by_frame": res["same"],
+                   "assembled_equals_single_rank": res["assembled_same"],
                    "color0_sha256": res["batched_hash"], "color0_sha256_frame_by_frame": res["fbf_hash"],
                    "self_check": ("COLOR0 of frame %d (last timed frame) after the batched run == after one rt_render_frame per frame over the same frame "
                                   "indices, sha256 of the RGBA16F bits%s" % (args.warmup + args.steps - 1, ", every rank its own tiles" if world > 1 else "")) if check else None,
@@ -584,6 +613,9 @@ def main():
         print(json.dumps(out))
     if check and res["same"] is False:
         sys.stderr.write("bench.py: batched frames differ from frame-by-frame rendering (COLOR0 %s vs %s)\n" % (res["batched_hash"], res["fbf_hash"]))
+        raise SystemExit(3)
+    if rank == 0 and res.get("assembled_same") is False:
+        sys.stderr.write("bench.py: the frame assembled from the ranks' tiles differs from the single-rank frame\n")
         raise SystemExit(3)
 
 

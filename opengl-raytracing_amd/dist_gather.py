@@ -46,6 +46,8 @@ class FrameGatherer:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.device = torch.device("cuda", torch.cuda.current_device())
+        # a gloo group (rehearsals with several ranks on ONE GPU, which RCCL refuses): blocks are staged through host memory
+        self.host_staged = bool(dist.is_initialized() and dist.get_backend(group) == "gloo")
         self._streams = {}
         self.block = renderer.gather_block_bytes(which)
         ch = TARGET_CHANNELS[which]
@@ -79,7 +81,13 @@ class FrameGatherer:
             stream = self._streams[sp] = torch.cuda.ExternalStream(sp, device=self.device)
         self.gathered, self.frame = self._pair(sp)
         with torch.cuda.stream(stream):
-            if self.world > 1:
+            if self.world > 1 and self.host_staged:
+                h = loc.cpu()                    # waits for the frame on this stream
+                parts = [torch.empty_like(h) for _ in range(self.world)] if self.rank == 0 else None
+                dist.gather(h, parts, dst=0, group=self.group)
+                if self.rank == 0:
+                    self.gathered.copy_(torch.stack(parts))
+            elif self.world > 1:
                 dist.gather(loc, list(self.gathered.unbind(0)) if self.rank == 0 else None, dst=0, group=self.group)
             elif self.rank == 0:
                 self.gathered[0].copy_(loc, non_blocking=True)

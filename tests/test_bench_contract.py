@@ -76,3 +76,20 @@ def test_bench_self_launch_rehearsal_world_of_one():
     d = _bench(SMALL + ["--cpu-seconds", "0", "--no-default-camera", "--launch", "--force-gather", "--gpus", "1"])
     assert d["n_gpus"] == 1 and d["config"]["gather"]["path"].startswith("library-owned RCCL")
     assert d["config"]["batched_equals_frame_by_frame"] is True
+
+
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_bench_ranks_as_processes_on_one_gpu(ranks):
+    """--gpus N --rehearse-one-gpu: bench.py starts N rank processes itself (the form the driver uses), every rank renders its tiles on GPU 0,
+    the group is gloo and the gathers are staged through the host (RCCL refuses two ranks on one device).  What this covers that no
+    one-process test can: the launch, RANK / WORLD_SIZE handling, barriers and max-over-ranks timing, counters summed over ranks, one gather
+    per batch from N processes -- and rank 0 compares the assembled frame with the one a single context renders, bit for bit."""
+    d = _bench(SMALL + ["--cpu-seconds", "0", "--no-default-camera", "--no-diagnostics", "--gpus", str(ranks), "--rehearse-one-gpu"], timeout=900)
+    assert d["n_gpus"] == ranks and d["scaling"] == "strong"
+    c = d["config"]
+    assert "gloo" in c["gather"]["path"] and "error" not in c["gather"]
+    assert c["batched_equals_frame_by_frame"] is True        # every rank: its own tiles
+    assert c["assembled_equals_single_rank"] is True
+    one = _bench(SMALL + ["--cpu-seconds", "0", "--no-default-camera", "--no-diagnostics"])
+    assert c["rays_per_frame"] == one["config"]["rays_per_frame"]   # the ranks' reference-unit counters add up to the whole frame's
+    assert c["hit_pixels"] == one["config"]["hit_pixels"]
