@@ -12,7 +12,8 @@
 // did was right and it is finished without being shaded again (with the reference's default camera the mesh stands between the floor and the
 // point light: nearly every sample has such a query, and about half of them miss the mesh); otherwise the answers up to the first such
 // hit of a query that later rays were built from (primary, bounce, reflection, refraction -- visibility hits leave the later queries valid) join the
-// log and the thread is shaded again from there.  At the end of a
+// log and the thread is shaded again from there -- in a pass over the DENSE list of such threads (k_hybrid_verify packs it), so that later passes
+// run whole waves of work instead of a few lanes per wave.  At the end of a
 // pass every wave appends the queue addresses of what its threads recorded to a dense list (one atomic per wave; query-major inside the
 // wave's block, so that neighbouring list entries are the same kind of ray of neighbouring pixels), and between two shading passes ONE
 // persistent closest-hit launch of the wavefront pipeline (k_trace over that list, rt_wave.hip) traces everything recorded.  A finished
@@ -33,6 +34,7 @@ using namespace rtd;
 namespace {
 
 constexpr uint32_t kDone = 0xffffffffu;
+constexpr uint32_t kCnt = 32;   // words between two counters: each on its own 128-byte line (they are hit by one atomic per workgroup)
 enum { ST_TRACE_GI = 6, ST_RESOLVE = 8, ST_COMBINE = 9 };   // stage ids shared with rt_wave.hip (rt_stage_name)
 
 struct HybridBuf {
@@ -44,19 +46,24 @@ struct HybridBuf {
     float4 *rad;           // [T] final radiance of (pixel, sample)
     float2 *sMotion;       // [nS] from the sample-0 thread: rt.frag:94-101, 172-175
     float4 *sPos, *sNrm;   // [nS]
-    uint32_t *cnt;         // [0] threads not finished [1] queries recorded (= entries of idx) [2] overflow
+    uint32_t *todo, *recd; // [T] dense lists of threads: to shade in this pass (behind the first pass) / that recorded queries in this pass
+    uint32_t *cnt;         // at [k * kCnt]: k = 0 threads that recorded (= entries of recd), 1 queries recorded (= entries of idx), 2 overflow, 3 entries of todo
     uint32_t slot0, nS, T, qmax;
     int SPP;
 };
 
 // Five waves per SIMD: 96 VGPRs and 704 bytes of scratch per lane.  The shading code is long and cold in most of its registers; measured on MI355X
 // (1080p, 16 spp, 4 bounces, all shading passes of a frame): 53.8 / 41.1 / 38.0 / 36.4 / 39.1 ms at 2 (no bound: 225 VGPRs) / 3 / 4 / 5 / 6 waves per SIMD.
-__global__ __launch_bounds__(256, 5) void k_hybrid_shade(const DevFrame *__restrict__ fr, HybridBuf hb) {
-    const uint32_t tid = blockIdx.x * 256u + threadIdx.x;
+__global__ __launch_bounds__(256, 5) void k_hybrid_shade(const DevFrame *__restrict__ fr, HybridBuf hb, int listed) {
+    // first pass of a chunk: thread = (sample, slot) in order; later passes: the threads k_hybrid_verify left to do, packed (whole waves of work
+    // instead of the few lanes per wave whose speculation failed: the second pass ran with 0.61 of its lanes, the third with 0.03)
+    const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n = listed ? hb.cnt[3 * kCnt] : hb.T;
+    const uint32_t tid = gid < n ? (listed ? hb.todo[gid] : gid) : 0u;
     bool open = false;
     uint32_t recorded = 0, known = 0;
-    if (tid < hb.T) {
+    if (gid < n) {
         const uint32_t st = hb.state[tid];
         if (st != kDone) {
             const RtUniforms &u = fr->u;
@@ -67,25 +74,8 @@ __global__ __launch_bounds__(256, 5) void k_hybrid_shade(const DevFrame *__restr
                 hb.rad[tid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // padding of a ragged tile: nothing to render
                 hb.state[tid] = kDone;
             } else {
-                // check last pass's speculation: queries [known, rec) were recorded and answered "no mesh hit" on the spot
-                uint32_t kn = st & 0xffffu;
-                const uint32_t rec = st >> 16;
-                bool finished = false;
-                if (rec > kn) {
-                    bool anyHit = false;
-                    uint32_t valid = rec;                  // answers [kn, valid) are answers to the queries the true frame asks
-                    for (uint32_t q = kn; q < rec; ++q) {
-                        const size_t a = (size_t)q * hb.T + tid;
-                        if (hb.logTri[a] >= 0 && hb.logT[a] < hb.o[a].w) {       // a mesh hit in front of the analytic scene's: the speculation failed here
-                            anyHit = true;
-                            if (hb.d[a].w != 0.0f) { valid = q + 1u; break; }      // later rays were built from the wrong hit: what follows is void
-                        }
-                    }
-                    if (!anyHit) finished = true;          // every speculated miss was one: the stored radiance is final
-                    else kn = valid;                       // shade again with these answers known
-                }
-                if (finished) { hb.state[tid] = kDone; }
-                else {
+                const uint32_t kn = st & 0xffffu;          // answers [0, kn) are in the log
+                {
                 Replay R;
                 R.known = kn;
                 R.thread = tid; R.stride = hb.T; R.qmax = hb.qmax;
@@ -118,7 +108,7 @@ __global__ __launch_bounds__(256, 5) void k_hybrid_shade(const DevFrame *__restr
                     radiance = sky<false>(F, dir, w);
                     if (u.cameraMoved == 1 && s == 0) motion = mk2(4.0f, 4.0f);
                 }
-                if (R.overflow) atomicOr(&hb.cnt[2], 1u);
+                if (R.overflow) atomicOr(&hb.cnt[2 * kCnt], 1u);
                 // the result of this pass is kept either way: final if nothing was open, else provisional until the next pass has checked the speculation
                 hb.rad[tid] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
                 if (s == 0) {
@@ -139,27 +129,76 @@ __global__ __launch_bounds__(256, 5) void k_hybrid_shade(const DevFrame *__restr
             }
         }
     }
-    // wave-level: count the open threads, reserve this wave's block of the dense list with ONE atomic, fill it query-major
+    // Each wave's share of the two dense lists (threads that recorded; the queue addresses they recorded, query-major inside the wave's block) is
+    // reserved with ONE atomic pair per WORKGROUP: a single counter word takes about 90 M atomics per second on MI355X, and one pair per wave
+    // (224 k waves in the first pass of a 1080p / 16 spp chunk) was most of that pass's time.
+    __shared__ uint32_t sOpen[4], sTot[4], sBase[2];
+    const uint32_t wv = threadIdx.x >> 6;
     const unsigned long long om = __ballot(open);
-    if (om == 0ull) return;
     uint32_t total = recorded, most = recorded;
     for (int off = 32; off > 0; off >>= 1) {
         total += (uint32_t)__shfl_down((int)total, off, 64);
         most = max(most, (uint32_t)__shfl_down((int)most, off, 64));
     }
-    uint32_t base = 0;
-    if (lane == 0u) {
-        atomicAdd(&hb.cnt[0], (uint32_t)__popcll(om));
-        base = total ? atomicAdd(&hb.cnt[1], total) : 0u;
+    if (lane == 0u) { sOpen[wv] = (uint32_t)__popcll(om); sTot[wv] = total; }
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        const uint32_t nOpen = sOpen[0] + sOpen[1] + sOpen[2] + sOpen[3], nTot = sTot[0] + sTot[1] + sTot[2] + sTot[3];
+        sBase[0] = nOpen ? atomicAdd(&hb.cnt[0], nOpen) : 0u;
+        sBase[1] = nTot ? atomicAdd(&hb.cnt[1 * kCnt], nTot) : 0u;
     }
-    base = (uint32_t)__shfl((int)base, 0, 64);
+    __syncthreads();
+    if (om == 0ull) return;
+    uint32_t tbase = sBase[0], base = sBase[1];
+    for (uint32_t k = 0; k < wv; ++k) { tbase += sOpen[k]; base += sTot[k]; }
     most = (uint32_t)__shfl((int)most, 0, 64);
     const unsigned long long lt = (1ull << lane) - 1ull;
+    if (open) hb.recd[tbase + (uint32_t)__popcll(om & lt)] = tid;      // whose speculation the next pass checks
     for (uint32_t k = 0; k < most; ++k) {
         const unsigned long long m = __ballot(recorded > k);
         if (recorded > k) hb.idx[base + (uint32_t)__popcll(m & lt)] = (known + k) * hb.T + tid;
         base += (uint32_t)__popcll(m);
     }
+}
+
+// Between a traversal launch and the next shading pass: every thread that recorded queries checks its speculation against the traced answers.
+// All of them misses (or hits behind the analytic scene's own): the thread is finished, its stored radiance final.  Otherwise the answers up to the
+// first failed query that later rays were built from join the log, and the thread goes onto the dense list of the next pass.
+__global__ __launch_bounds__(256) void k_hybrid_verify(HybridBuf hb) {
+    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    bool again = false;
+    uint32_t tid = 0;
+    if (j < hb.cnt[0]) {
+        tid = hb.recd[j];
+        const uint32_t st = hb.state[tid];
+        const uint32_t kn = st & 0xffffu, rec = st >> 16;
+        bool anyHit = false;
+        uint32_t valid = rec;                      // answers [kn, valid) are answers to queries the true frame asks
+        for (uint32_t q = kn; q < rec; ++q) {
+            const size_t a = (size_t)q * hb.T + tid;
+            if (hb.logTri[a] >= 0 && hb.logT[a] < hb.o[a].w) {        // a mesh hit in front of the analytic scene's: the speculation failed here
+                anyHit = true;
+                if (hb.d[a].w != 0.0f) { valid = q + 1u; break; }      // later rays were built from the wrong hit: what follows is void
+            }
+        }
+        if (!anyHit) hb.state[tid] = kDone;        // every speculated miss was one
+        else { hb.state[tid] = valid; again = true; }
+    }
+    __shared__ uint32_t sAgain[4], sBase;
+    const uint32_t wv = threadIdx.x >> 6;
+    const unsigned long long am = __ballot(again);
+    if (lane == 0u) sAgain[wv] = (uint32_t)__popcll(am);
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        const uint32_t nAgain = sAgain[0] + sAgain[1] + sAgain[2] + sAgain[3];
+        sBase = nAgain ? atomicAdd(&hb.cnt[3 * kCnt], nAgain) : 0u;      // one atomic per workgroup (see k_hybrid_shade)
+    }
+    __syncthreads();
+    if (!again) return;
+    uint32_t base = sBase;
+    for (uint32_t k = 0; k < wv; ++k) base += sAgain[k];
+    hb.todo[base + (uint32_t)__popcll(am & ((1ull << lane) - 1ull))] = tid;
 }
 
 // thread = pixel: the sample sum in the shader's order (rt.frag:79-184), TAA resolve, four target stores -- the tail of k_mega
@@ -242,7 +281,7 @@ int rt_hybrid_render(RtHybrid *h, RtContext *ctx, hipStream_t st, const DevFrame
     // mesh queries of one sample, worst case (every ray meets the mesh's root box): primary 1, direct 6, AO aoSamples, per bounce 1 + 6;
     // mirror: 1 + 6 more in front of its bounces; glass: 3 x (1 + 6).  A thread that needs more ends the frame with RT_ERR_UNSUPPORTED.
     const uint32_t qmax = (uint32_t)(1 + 6 + std::max(u.aoSamples, 0) + 7 * std::max(host.giBounces, 1) + 7 + 8);
-    const size_t perThread = (size_t)qmax * (16 + 16 + 4 + 4 + 4) + 4 + 16, perSlot = (size_t)SPP * perThread + 8 + 16 + 16;
+    const size_t perThread = (size_t)qmax * (16 + 16 + 4 + 4 + 4) + 3 * 4 + 16, perSlot = (size_t)SPP * perThread + 8 + 16 + 16;
     size_t nS = std::min(nSlots, std::max<size_t>(h->budgetBytes / perSlot, 256));
     nS = std::max<size_t>(nS / 256 * 256, 256);
     const size_t Tmax = nS * (size_t)SPP;
@@ -251,7 +290,7 @@ int rt_hybrid_render(RtHybrid *h, RtContext *ctx, hipStream_t st, const DevFrame
         nS = std::max<size_t>((((size_t)1 << 31) - 1) / ((size_t)qmax * SPP) / 256 * 256, 256);
     }
     const size_t T0 = nS * (size_t)SPP, Q = (size_t)qmax * T0;
-    const size_t need = align_up(Q * 16, 256) * 2 + align_up(Q * 4, 256) * 3 + align_up(T0 * 4, 256) + align_up(T0 * 16, 256) + align_up(nS * 8, 256) +
+    const size_t need = align_up(Q * 16, 256) * 2 + align_up(Q * 4, 256) * 3 + align_up(T0 * 4, 256) * 3 + align_up(T0 * 16, 256) + align_up(nS * 8, 256) +
                         align_up(nS * 16, 256) * 2 + 4096;
     if (h->arenaBytes < need) {
         if (h->arena) (void)hipFree(h->arena);
@@ -260,9 +299,9 @@ int rt_hybrid_render(RtHybrid *h, RtContext *ctx, hipStream_t st, const DevFrame
         h->arenaBytes = need;
     }
     if (!h->cnt) {
-        H_TRY(hipMalloc((void **)&h->cnt, 16 * sizeof(uint32_t)));
+        H_TRY(hipMalloc((void **)&h->cnt, 4 * kCnt * sizeof(uint32_t)));
         H_TRY(hipMalloc((void **)&h->heads, rt_wave_head_words() * sizeof(uint32_t)));
-        H_TRY(hipHostMalloc((void **)&h->hostCnt, 16 * sizeof(uint32_t)));
+        H_TRY(hipHostMalloc((void **)&h->hostCnt, 4 * kCnt * sizeof(uint32_t)));
     }
     HybridBuf hb;
     {
@@ -270,7 +309,7 @@ int rt_hybrid_render(RtHybrid *h, RtContext *ctx, hipStream_t st, const DevFrame
         auto take = [&](size_t bytes) { char *r = q; q += align_up(bytes, 256); return r; };
         hb.o = (float4 *)take(Q * 16); hb.d = (float4 *)take(Q * 16);
         hb.idx = (uint32_t *)take(Q * 4); hb.logT = (float *)take(Q * 4); hb.logTri = (int *)take(Q * 4);
-        hb.state = (uint32_t *)take(T0 * 4); hb.rad = (float4 *)take(T0 * 16);
+        hb.state = (uint32_t *)take(T0 * 4); hb.todo = (uint32_t *)take(T0 * 4); hb.recd = (uint32_t *)take(T0 * 4); hb.rad = (float4 *)take(T0 * 16);
         hb.sMotion = (float2 *)take(nS * 8); hb.sPos = (float4 *)take(nS * 16); hb.sNrm = (float4 *)take(nS * 16);
     }
     hb.cnt = h->cnt; hb.qmax = qmax; hb.SPP = SPP;
@@ -281,26 +320,36 @@ int rt_hybrid_render(RtHybrid *h, RtContext *ctx, hipStream_t st, const DevFrame
         hb.slot0 = (uint32_t)slot0; hb.nS = (uint32_t)nSc; hb.T = (uint32_t)T;
         // the queue of a smaller last chunk uses stride T as well: entries stay inside the arena (T <= T0)
         H_TRY(hipMemsetAsync(hb.state, 0, T * 4, st));
+        uint32_t todoBound = 0;                        // upper bound of the dense list's length: the threads that recorded in the pass before
         for (int pass = 0;; ++pass) {
             if (pass > 4 * (int)qmax) { h->err = "hybrid: passes do not converge"; return RT_ERR_STATE; }
-            H_TRY(hipMemsetAsync(h->cnt, 0, 4 * sizeof(uint32_t), st));
+            // cnt[0..2] belong to the shading pass about to run; cnt[3] (entries of todo) was written by the verification just before it
+            H_TRY(hipMemsetAsync(h->cnt, 0, 3 * kCnt * sizeof(uint32_t), st));
             rt_stage_begin(ctx, ST_COMBINE, st);
-            hipLaunchKernelGGL(k_hybrid_shade, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, st, dFrame, hb);
+            const size_t threads = pass == 0 ? T : (size_t)todoBound;
+            hipLaunchKernelGGL(k_hybrid_shade, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, dFrame, hb, pass == 0 ? 0 : 1);
             rt_stage_end(ctx, ST_COMBINE, 1, st);
-            H_TRY(hipMemcpyAsync(h->hostCnt, h->cnt, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            H_TRY(hipMemcpyAsync(h->hostCnt, h->cnt, 4 * kCnt * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             H_TRY(hipStreamSynchronize(st));
             h->passes++;
-            const uint32_t open = h->hostCnt[0], recorded = h->hostCnt[1], overflow = h->hostCnt[2];
-            if (h->debug) fprintf(stderr, "[hybrid] slots %zu..%zu pass %d: %u of %zu threads open, %u queries recorded\n", slot0, slot0 + nSc, pass, open, T, recorded);
+            const uint32_t open = h->hostCnt[0], recorded = h->hostCnt[1 * kCnt], overflow = h->hostCnt[2 * kCnt];
+            if (h->debug) fprintf(stderr, "[hybrid] slots %zu..%zu pass %d: %zu threads shaded, %u of them recorded %u queries\n", slot0, slot0 + nSc, pass,
+                                  pass == 0 ? T : (size_t)h->hostCnt[3 * kCnt], open, recorded);
             if (overflow) { h->err = "hybrid: a sample needs more than " + std::to_string(qmax) + " mesh queries"; return RT_ERR_UNSUPPORTED; }
             if (open == 0) break;
             if (recorded == 0) { h->err = "hybrid: open queries but nothing recorded"; return RT_ERR_STATE; }
             H_TRY(hipMemsetAsync(h->heads, 0, rt_wave_head_words() * sizeof(uint32_t), st));
             rt_stage_begin(ctx, ST_TRACE_GI, st);
             // cnt[1] stays what the shading pass left there until the next pass clears it: the launch reads the list length from it
-            rt_wave_trace_closest_indexed(st, h->cus, treeDepth, dFrame, host.sc, hb.idx, &h->cnt[1], hb.o, hb.d, hb.logT, hb.logTri, h->heads);
+            rt_wave_trace_closest_indexed(st, h->cus, treeDepth, dFrame, host.sc, hb.idx, &h->cnt[1 * kCnt], hb.o, hb.d, hb.logT, hb.logTri, h->heads);
             rt_stage_end(ctx, ST_TRACE_GI, 1, st);
             h->launches++;
+            // the threads that recorded check their speculation; who failed is packed into the next pass's list
+            H_TRY(hipMemsetAsync(h->cnt + 3 * kCnt, 0, sizeof(uint32_t), st));
+            rt_stage_begin(ctx, ST_COMBINE, st);
+            hipLaunchKernelGGL(k_hybrid_verify, dim3((unsigned)((open + 255u) / 256u)), dim3(256), 0, st, hb);
+            rt_stage_end(ctx, ST_COMBINE, 1, st);
+            todoBound = open;
         }
         if (!waited && evPrevDone) { H_TRY(hipStreamWaitEvent(st, evPrevDone, 0)); waited = true; }   // the resolve reads the previous frame's COLOR0
         rt_stage_begin(ctx, ST_RESOLVE, st);
