@@ -50,10 +50,16 @@ L1_ACCESS_PEAK_G = CUS * PEAK_CLOCK_HZ / 1e9
 W, H, SPP = 1920, 1080, 4
 
 
+TRAVERSAL_SOURCES = ("rt_wave.hip", "rt_wave.hpp", "rt_api.hip", "rt_frame.hpp", "rt_device_shade.hpp", "rt_device_math.hpp", "rt_device_analytic.hpp")
+
+
 def kernel_source_sha():
-    """sha256 over the device sources: ties a committed PMC traffic figure to the kernels it was measured on."""
+    """sha256 over the sources that determine the wavefront pipeline's launches (its kernels, the headers they include, and the host file that lays
+    out the trees and queues): ties a committed PMC traffic figure to the code it was measured on.  The megakernel, the hybrid extension's passes, the
+    present pass and the GPU tree builder are not on the benchmarked path and do not enter."""
     h = hashlib.sha256()
-    for f in sorted((ROOT / "opengl-raytracing_amd" / "csrc").glob("*.h*")):
+    for name in sorted(TRAVERSAL_SOURCES):
+        f = ROOT / "opengl-raytracing_amd" / "csrc" / name
         h.update(f.name.encode())
         h.update(f.read_bytes())
     return h.hexdigest()

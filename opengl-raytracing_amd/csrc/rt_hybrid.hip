@@ -237,7 +237,10 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 struct RtHybrid {
     std::string err;
     int cus = 256;
-    size_t budgetBytes = (size_t)32 << 30;   // ONE arena per context, shared by the frame lanes (evFree): 32 GB of the 288 keep a 1080p / 16 spp frame to three chunks
+    // ONE arena per context, shared by the frame lanes (evFree) and allocated for what the frame needs: 96 GB of the 288 hold a 1080p / 16 spp / 4-bounce
+    // frame (80 GB: 33 M threads x 54 queries x 44 B) in ONE chunk -- 30.5 / 29.4 / 28.5 ms per frame with 32 / 48 / 96 GB (three / two / one chunk: each chunk has
+    // its own tail of nearly empty passes)
+    size_t budgetBytes = (size_t)96 << 30;
     hipEvent_t evFree = nullptr;          // recorded after a frame's last kernel: the next frame (another lane's stream) waits for it before it touches the arena
     void *arena = nullptr;
     size_t arenaBytes = 0;

@@ -55,7 +55,8 @@ for k, d in sorted(agg.items()):
                  "hbm_bytes_corrected": (2 * d.get("FETCH_SIZE", 0) + d.get("WRITE_SIZE", 0)) * 1024,
                  "tcp_cache_accesses": d.get("TCP_TOTAL_CACHE_ACCESSES_sum"), "tcp_accesses_per_clk_per_cu": acc_per_clk}
 h = hashlib.sha256()
-for f in sorted((pathlib.Path(__file__).resolve().parent.parent / "opengl-raytracing_amd" / "csrc").glob("*.h*")):   # = bench.py kernel_source_sha()
+for name in sorted(("rt_wave.hip", "rt_wave.hpp", "rt_api.hip", "rt_frame.hpp", "rt_device_shade.hpp", "rt_device_math.hpp", "rt_device_analytic.hpp")):   # = bench.py kernel_source_sha()
+    f = pathlib.Path(__file__).resolve().parent.parent / "opengl-raytracing_amd" / "csrc" / name
     h.update(f.name.encode())
     h.update(f.read_bytes())
 json.dump({"kernel_source_sha256": h.hexdigest(), "commit": None, "mode": "bench.py timed mode: rt_render_frames in batches of 8, RT_LANES=1 under the profiler",
