@@ -114,6 +114,9 @@ def parse_args(argv=None):
     ap.add_argument("--hybrid", action="store_true", help="EXTENSION (not in the reference; SURVEY 8d config 3 run B): the analytic scene "
                     "(floor, glass / mirror / diffuse spheres) with the mesh added to it, reference default camera")
     ap.add_argument("--gi-bounces", type=int, default=1, help="EXTENSION: diffuse bounces of the analytic / hybrid GI path (configs[2]: 4)")
+    ap.add_argument("--parity-window", default="64x32", help="WxH of the oracle window around the frame centre that the last timed frame is compared "
+                    "with after the timed run (full history chain from frame 0, all host threads); 0 = skip the parity block")
+    ap.add_argument("--n1-ms", type=float, default=None, help="N > 1: ms_per_step of the same workload on one GPU -> config.multi_gpu.efficiency_vs_n1")
     return ap.parse_args(argv)
 
 
@@ -313,6 +316,9 @@ def main():
         ren.traced_rays(reset=True)
         if timed_stage:
             ren.enable_stage_timing(True)
+            if isinstance(gatherer, FrameGatherer):
+                gatherer.timed = True
+        comm0 = ren.comm_info() if multi else None
         if multi:
             dist.barrier()
         torch.cuda.synchronize()
@@ -320,6 +326,7 @@ def main():
         run_steps(warmup, warmup + steps)
         ren.synchronize()
         torch.cuda.synchronize()
+        dt_own = time.perf_counter() - t0          # this rank alone: its frames and its share of the gathers (the line's per_rank_ms)
         if multi:
             dist.barrier()
         dt = time.perf_counter() - t0
@@ -327,6 +334,19 @@ def main():
         traced = ren.traced_rays()
         info = ren.scene_info()
         batched_hash = color_hash(ren) if check else None
+        comm = ren.comm_info() if multi else None
+        if comm is not None:        # gathers of the timed region only
+            comm.gathers -= comm0.gathers
+            comm.gatherBytes -= comm0.gatherBytes
+        gather_py = gatherer.timing() if (multi and hasattr(gatherer, "timing")) else None
+        # what the parity block compares with the oracle: one GPU -- all four targets of the last timed frame; tile-parallel -- the COLOR0
+        # frame rank 0 assembled from every rank's tiles in the last gather (so the exchange itself is inside the comparison)
+        final_targets = None
+        if parity_wanted and timed_stage:
+            if multi:
+                final_targets = [gatherer.frame_halfs()] if rank == 0 else None
+            else:
+                final_targets = ren.read_all()
         assembled_same = None
         if args.rehearse_one_gpu and gatherer is not None and world > 1:
             # rank 0: the frame the ranks' tiles were assembled into == the same frames rendered by one context that owns every tile
@@ -375,7 +395,8 @@ def main():
             dist.all_reduce(tr, op=dist.ReduceOp.SUM)
         frames_all = max(int(tr[1].item()) // world, 1)
         traced_per_frame = int(tr[0].item()) // frames_all if traced.frames else 0
-        return {"seconds": float(tt.item()), "counters": total, "local_counters": cnt, "stages": stages,
+        return {"seconds": float(tt.item()), "seconds_own": dt_own, "comm": comm, "gather_py": gather_py, "final_targets": final_targets, "frames_u": frames_u,
+                "counters": total, "local_counters": cnt, "stages": stages,
                 "traced_per_frame": traced_per_frame, "traced": traced, "scene_info": info, "counted_frames": steps,
                 "batched_hash": batched_hash, "fbf_hash": fbf_hash, "fbf_ms": fbf_ms, "same": bool(same.item()) if check else None,
                 "assembled_same": assembled_same}
@@ -388,6 +409,8 @@ def main():
         nodes, tris = rt.build_bvh(rt.gather_triangles(v_, f_, M.T.reshape(-1)))
     cam_kind = "default" if args.hybrid else "closeup"
     check = not args.no_frame_by_frame
+    pw = [int(v) for v in args.parity_window.lower().split("x")] if args.parity_window not in ("0", "", "0x0") else None
+    parity_wanted = pw is not None
     res = run_camera(scenes.camera(cam_kind), args.steps, args.warmup, check=check)
 
     # ---- diagnostics, untimed, single GPU: (1) one launch set in flight (RT_LANES=1) in the SAME batched mode as the timed run: what each
@@ -569,6 +592,72 @@ def main():
     if serial:
         out["stage_ms_per_frame_one_launch_set_in_flight"] = {k: v["ms"] / serial["frames"] for k, v in serial["stages"].items()}
 
+    # ---- multi-GPU: what each rank did, gathered over the ranks, so that ONE line explains an N-GPU figure (no scaling curve has been measured
+    # anywhere yet: SCALE_r01-r03 were skipped).  per_rank_ms: every rank's own time from the common start to the end of its own work (its
+    # frames + its side of the gathers), before the closing barrier; gather: HIP events around each rt_gather_frame on the stream it runs on.
+    if multi:
+        g_stage = (st or {"stages": {}})["stages"].get("gather")
+        gp = res["gather_py"]
+        own = [res["seconds_own"] / args.steps * 1e3,
+               (g_stage["ms"] if g_stage else (gp["ms"] if gp else 0.0)),
+               float(g_stage["launches"] if g_stage else (gp["gathers"] if gp else 0)),
+               float(res["comm"].gatherBytes if g_stage else (gp["bytes"] if gp else 0)),
+               float(res["comm"].commWorld), float(res["comm"].commRank),
+               1.0 if "error" in gather_path else 0.0, float(local_rank)]
+        mine = torch.tensor(own, dtype=torch.float64, device="cuda")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        rows = [[float(v) for v in t.tolist()] for t in allr]
+        ms_r = [r[0] for r in rows]
+        root = rows[0]
+        g_ms = root[1] / max(root[2], 1.0)
+        out["config"]["multi_gpu"] = {
+            "per_rank_ms": {"min": min(ms_r), "max": max(ms_r), "mean": sum(ms_r) / len(ms_r), "values": ms_r,
+                            "what": "per step; each rank's own host clock from the common start (barrier) to the end of its own frames and gathers"},
+            "imbalance": max(ms_r) / (sum(ms_r) / len(ms_r)),
+            "gather_ms_per_batch": g_ms, "gathers": int(root[2]), "gather_bytes": int(root[3] / max(root[2], 1.0)),
+            "gather_GBps": (root[3] / max(root[2], 1.0)) / (g_ms * 1e-3) / 1e9 if g_ms > 0 else None,
+            "gather_what": "rank 0: HIP events on the gathered frame's stream from the moment that stream reaches the exchange to the end of the "
+                           "un-tiling kernel (so it includes waiting for the slowest sender); bytes = what rank 0 receives per gather",
+            "gather_ms_per_batch_by_rank": [r[1] / max(r[2], 1.0) for r in rows],
+            "rccl_world": [int(r[4]) for r in rows], "rccl_rank": [int(r[5]) for r in rows],
+            "rccl_world_what": "ncclCommCount / ncclCommUserRank of the library's communicator on every rank (-1: no communicator on that rank -- "
+                               "the exchange then ran through torch.distributed, see config.gather.path)",
+            "fallback": [bool(r[6]) for r in rows], "device": [int(r[7]) for r in rows],
+            "efficiency_vs_n1": (args.n1_ms / ms_per_step / world) if args.n1_ms else None,
+            "scaling_curve": "not measured in any round so far; this line is one point",
+        }
+
+    # ---- parity of the timed frames (BASELINE.json's metric has an RMSE leg): the last timed frame -- warm-up + steps frames deep in the
+    # accumulation -- against the oracle (oracle/: the scalar CPU restatement of shaders/rt, the checker) on a window around the frame centre,
+    # the whole history chain rendered by the oracle on all host threads.  Untimed.  rmse >= 1e-4 on any target ends the run with exit code 4.
+    # The reference's own precision anchor is the fp16 targets (rt.frag:29-38, src/render/accum.cpp:10); HIP == oracle is asserted bit for bit
+    # in tests/, so bit_diff is expected to be 0 and rmse exactly 0.
+    parity = None
+    if parity_wanted and rank == 0 and res["final_targets"] is not None:
+        import oracle as orc
+        t_p = time.perf_counter()
+        x0 = max(0, min(W - pw[0], W // 2 - pw[0] // 2)); y0 = max(0, min(H - pw[1], H // 2 - pw[1] // 2))
+        x1, y1 = min(W, x0 + pw[0]), min(H, y0 + pw[1])
+        prev, want = None, None
+        for u_f in res["frames_u"]:
+            want, _ = orc.render(u_f, nodes, tris, faces, prev, region=(x0, y0, x1, y1), nthreads=usable_cores(), gi_bounces=args.gi_bounces)
+            prev = want[0]
+        names = ("color", "motion", "gpos", "gnrm")
+        per = {}
+        for g_t, w_t, nm in zip(res["final_targets"], want, names):
+            c_ = orc.compare(np.ascontiguousarray(g_t[y0:y1, x0:x1]), np.ascontiguousarray(w_t[y0:y1, x0:x1]))
+            per[nm] = {"rmse": c_["rmse"], "max_abs": c_["max_abs"], "outliers_gt_1e-2": c_["outliers"], "bit_diff": c_["bit_diff"]}
+        worst = max(v["rmse"] for v in per.values())
+        parity = {"vs": "oracle", "window": [x0, y0, x1, y1], "frame": args.warmup + args.steps - 1, "frames_chained": len(res["frames_u"]),
+                  "targets": per, "rmse": worst, "max_abs": max(v["max_abs"] for v in per.values()),
+                  "outliers_gt_1e-2": sum(v["outliers_gt_1e-2"] for v in per.values()), "bit_diff": sum(v["bit_diff"] for v in per.values()),
+                  "tolerance": "rmse < 1e-4 per target (north_star); values are RGBA16F / RG16F half floats compared as floats",
+                  "compared": ("COLOR0 of the frame rank 0 assembled from all ranks' tiles (last gather)" if multi else
+                               "all four targets of the last timed frame, as left by the batched timed run"),
+                  "oracle_seconds": time.perf_counter() - t_p, "ok": bool(worst < 1e-4)}
+    out["parity"] = parity
+
     if not args.no_default_camera and not args.hybrid:
         d = run_camera(scenes.camera("default"), args.steps, args.warmup, timed_stage=False)
         out["default_camera"] = {"value": d["counters"].rays / d["seconds"] / 1e6, "unit": "Mray/s",
@@ -620,6 +709,9 @@ def main():
     if check and res["same"] is False:
         sys.stderr.write("bench.py: batched frames differ from frame-by-frame rendering (COLOR0 %s vs %s)\n" % (res["batched_hash"], res["fbf_hash"]))
         raise SystemExit(3)
+    if parity is not None and not parity["ok"]:
+        sys.stderr.write("bench.py: the timed frame differs from the oracle: %s\n" % json.dumps(parity["targets"]))
+        raise SystemExit(4)
     if rank == 0 and res.get("assembled_same") is False:
         sys.stderr.write("bench.py: the frame assembled from the ranks' tiles differs from the single-rank frame\n")
         raise SystemExit(3)

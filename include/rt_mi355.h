@@ -268,6 +268,11 @@ int rt_gathered_frame(RtContext *ctx, int which, void **devPtr, size_t *bytes); 
 int rt_read_gathered(RtContext *ctx, int which, void *dstHalfs);       /* rank 0: synchronises, copies that frame to the host */
 int rt_present_last_gathered(RtContext *ctx, const RtPresentParams *p, uint8_t *dstRGBA8);   /* rank 0, after rt_gather_frame of all 4 targets */
 int rt_exchange_history(RtContext *ctx);                               /* all-gather of COLOR0 + rt_history_exchanged() */
+/* What the communicator itself reports (ncclCommCount / ncclCommUserRank; -1 = no communicator) and what the gathers of this
+ * context moved: a tile-parallel run's line can then say which exchange really ran (bench.py's config.gather).  Device time of
+ * the gathers: stage "gather" of rt_get_stage_times.  bytesIn: bytes received by the gathering rank (others: bytes sent). */
+typedef struct RtCommInfo { int32_t commWorld, commRank, rank, worldSize; uint64_t gathers, gatherBytes, historyExchanges; } RtCommInfo;
+int rt_comm_info(RtContext *ctx, RtCommInfo *out);
 
 int rt_get_counters(RtContext *ctx, RtCounters *out);   /* needs countWork; totals since rt_reset_counters */
 int rt_reset_counters(RtContext *ctx);
@@ -298,7 +303,7 @@ int rt_get_traced_rays(RtContext *ctx, RtTracedRays *out, int reset);
 
 /* Device timing of the dominant kernel(s): HIP events recorded on the context's stream around each
  * stage of every frame since the last reset.  stage names: rt_stage_name(i). */
-#define RT_MAX_STAGES 12
+#define RT_MAX_STAGES 13
 typedef struct RtStageTimes { int32_t nStages; int32_t frames; double ms[RT_MAX_STAGES]; uint64_t launches[RT_MAX_STAGES]; } RtStageTimes;
 int rt_enable_stage_timing(RtContext *ctx, int enable);
 int rt_get_stage_times(RtContext *ctx, RtStageTimes *out);   /* synchronises */

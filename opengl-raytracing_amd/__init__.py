@@ -25,7 +25,7 @@ RT_TARGET_COLOR, RT_TARGET_MOTION, RT_TARGET_GPOS, RT_TARGET_GNRM = 0, 1, 2, 3
 RT_FORMAT_F16, RT_FORMAT_F32 = 0, 1
 RT_PIPELINE_AUTO, RT_PIPELINE_MEGAKERNEL, RT_PIPELINE_WAVEFRONT = 0, 1, 2
 TARGET_CHANNELS = {0: 4, 1: 2, 2: 4, 3: 4}
-RT_MAX_STAGES = 12
+RT_MAX_STAGES = 13
 RT_COMM_ID_BYTES = 128
 
 f32, i32 = C.c_float, C.c_int32
@@ -123,6 +123,10 @@ class RtStageTimes(_Struct):
     _fields_ = [("nStages", i32), ("frames", i32), ("ms", C.c_double * RT_MAX_STAGES), ("launches", C.c_uint64 * RT_MAX_STAGES)]
 
 
+class RtCommInfo(_Struct):
+    _fields_ = [(n, i32) for n in ("commWorld", "commRank", "rank", "worldSize")] + [(n, C.c_uint64) for n in ("gathers", "gatherBytes", "historyExchanges")]
+
+
 class RtTracedRays(_Struct):
     _fields_ = [(n, C.c_uint64) for n in ("candidatePixels", "hitPixels", "primary", "shadow", "bounce", "bounceShadow", "frames",
                                              "gatherLoadsPrimary", "gatherLoadsShadow", "gatherLoadsBounce",
@@ -197,6 +201,7 @@ SIGNATURES = {
     "rt_read_gathered": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "rt_present_last_gathered": (C.c_int, [C.c_void_p, C.POINTER(RtPresentParams), _U8P]),
     "rt_exchange_history": (C.c_int, [C.c_void_p]),
+    "rt_comm_info": (C.c_int, [C.c_void_p, C.POINTER(RtCommInfo)]),
     "rt_get_counters": (C.c_int, [C.c_void_p, C.POINTER(RtCounters)]),
     "rt_reset_counters": (C.c_int, [C.c_void_p]),
     "rt_get_scene_info": (C.c_int, [C.c_void_p, C.POINTER(RtSceneInfo)]),
@@ -603,6 +608,12 @@ class Renderer:
     def exchange_history(self):
         """All-gather of the last frame's COLOR0 blocks so that the next frame may reproject across tiles (moving camera)."""
         self._check(lib().rt_exchange_history(self._h))
+
+    def comm_info(self) -> RtCommInfo:
+        """What the RCCL communicator reports about itself (commWorld / commRank, -1 without one) + gather counts and bytes of this context."""
+        i = RtCommInfo()
+        self._check(lib().rt_comm_info(self._h, C.byref(i)))
+        return i
 
     def local_target(self, which):
         p, n = C.c_void_p(), C.c_size_t()

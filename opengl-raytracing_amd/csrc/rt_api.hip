@@ -79,6 +79,7 @@ struct RtContext {
     bool timing = false;
     std::vector<StageEvent> pending;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> freeEvents;
+    uint64_t gathers = 0, gatherBytes = 0, historyExchanges = 0;   // rt_comm_info
     double stageMs[RT_MAX_STAGES] = {0};
     uint64_t stageLaunches[RT_MAX_STAGES] = {0};
     int timedFrames = 0;
@@ -112,7 +113,8 @@ static hipError_t sync_all(RtContext *c) {
     } while (0)
 
 static const char *kStageNames[RT_MAX_STAGES] = {"mega",     "primary", "trace_primary",   "post_primary", "gen_direct", "trace_shadow",
-                                                 "trace_gi", "gen_gi",  "resolve",         "combine",      "assemble",   "present"};
+                                                 "trace_gi", "gen_gi",  "resolve",         "combine",      "assemble",   "present",
+                                                 "gather"};   // gather: the whole of rt_gather_frame on its stream (copy / send / recv / un-tiling; "assemble" lies inside it)
 
 // ------------------------------------------------------------------------------------------------
 namespace {
@@ -1126,7 +1128,7 @@ int rt_get_stage_times(RtContext *c, RtStageTimes *out) {
     if (!c || !out) return RT_ERR_INVALID;
     (void)hipSetDevice(c->cfg.device);
     resolve_stage_events(c);
-    out->nStages = 12;
+    out->nStages = RT_MAX_STAGES;
     out->frames = c->timedFrames;
     for (int i = 0; i < RT_MAX_STAGES; ++i) { out->ms[i] = c->stageMs[i]; out->launches[i] = c->stageLaunches[i]; }
     return RT_OK;
@@ -1190,6 +1192,8 @@ struct RcclApi {
     decltype(&ncclRecv) recv = nullptr;
     decltype(&ncclAllGather) allGather = nullptr;
     decltype(&ncclGetErrorString) errorString = nullptr;
+    decltype(&ncclCommCount) commCount = nullptr;          // optional (rt_comm_info)
+    decltype(&ncclCommUserRank) commUserRank = nullptr;
     std::string err;
     bool ok = false;
 };
@@ -1211,6 +1215,8 @@ static void rccl_bind(RcclApi &a) {
     RT_BIND(groupStart, ncclGroupStart); RT_BIND(groupEnd, ncclGroupEnd); RT_BIND(send, ncclSend); RT_BIND(recv, ncclRecv);
     RT_BIND(allGather, ncclAllGather); RT_BIND(errorString, ncclGetErrorString);
 #undef RT_BIND
+    a.commCount = (decltype(a.commCount))dlsym(h, "ncclCommCount");
+    a.commUserRank = (decltype(a.commUserRank))dlsym(h, "ncclCommUserRank");
     a.ok = true;
 }
 #define NCCL_TRY(c, expr)                                                                                           \
@@ -1298,8 +1304,17 @@ int rt_gather_frame(RtContext *c, int which) {
     if (root) {
         if (!c->dGathered[lane][which]) HIP_TRY(c, hipMalloc(&c->dGathered[lane][which], block * (size_t)c->g.world));
         if (!c->dAssembled[lane][which]) HIP_TRY(c, hipMalloc(&c->dAssembled[lane][which], (size_t)c->g.W * c->g.H * ch * 2));
-        HIP_TRY(c, hipMemcpyAsync(c->dGathered[lane][which], local, block, hipMemcpyDeviceToDevice, st));
     }
+    // stage "gather": from the point the lane's stream reaches the exchange (its frame is done) to the end of the un-tiling on the root / of
+    // the send on the others -- on the root this is what the first 8-GPU run needs to see next to the ranks' frame times (bench.py)
+    struct GatherSpan {
+        RtContext *c; hipStream_t st;
+        GatherSpan(RtContext *c_, hipStream_t s_) : c(c_), st(s_) { rt_stage_begin(c, 12, st); }
+        ~GatherSpan() { rt_stage_end(c, 12, 1, st); }
+    } span(c, st);
+    c->gathers++;
+    c->gatherBytes += root ? block * (size_t)(c->g.world - 1) : block;
+    if (root) HIP_TRY(c, hipMemcpyAsync(c->dGathered[lane][which], local, block, hipMemcpyDeviceToDevice, st));
     if (c->g.world > 1) {
         RcclApi &a = rccl_api();
         ncclComm_t comm = (ncclComm_t)c->comm;
@@ -1375,7 +1390,23 @@ int rt_exchange_history(RtContext *c) {
     const size_t block = c->nSlots * 8;
     if (c->g.world > 1) NCCL_TRY(c, rccl_api().allGather(c->dColor[lane], buf, block, ncclUint8, (ncclComm_t)c->comm, c->lanes[lane]));
     else HIP_TRY(c, hipMemcpyAsync(buf, c->dColor[lane], block, hipMemcpyDeviceToDevice, c->lanes[lane]));
+    c->historyExchanges++;
     return rt_history_exchanged(c);
+}
+
+int rt_comm_info(RtContext *c, RtCommInfo *out) {
+    if (!c || !out) return RT_ERR_INVALID;
+    out->commWorld = out->commRank = -1;
+    out->rank = c->cfg.rank; out->worldSize = c->cfg.worldSize;
+    out->gathers = c->gathers; out->gatherBytes = c->gatherBytes; out->historyExchanges = c->historyExchanges;
+    if (c->comm) {
+        RcclApi &a = rccl_api();
+        int v = -1;
+        if (a.commCount && a.commCount((ncclComm_t)c->comm, &v) == ncclSuccess) out->commWorld = v;
+        v = -1;
+        if (a.commUserRank && a.commUserRank((ncclComm_t)c->comm, &v) == ncclSuccess) out->commRank = v;
+    }
+    return RT_OK;
 }
 
 }  // extern "C"

@@ -355,6 +355,38 @@ RT_DEV void pin(float4 &v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), 
 typedef float v4f __attribute__((ext_vector_type(4)));
 RT_DEV void pin(v4f &v) { asm volatile("" : "+v"(v)); }
 
+// ---- quad-cooperative record fetch (round 4; microbenchmark tools/gather2.hip) ------------------------------------
+// The four lanes of a quad fetch ONE 64-byte record per instruction -- lane q piece q of the record quad-lane k stands on, k = 0..3 -- so a
+// quad's load touches one line instead of four; a 4x4 transpose inside the quad (two butterfly stages of v_cndmask_b32_dpp: the select and the
+// cross-lane read in one instruction, 32 per record set) then gives every lane the four pieces of ITS record.  Arithmetic and visit order are
+// untouched.  All 64 lanes must be enabled where this runs (DPP reads of disabled lanes return the old destination).
+template <int CTRL> RT_DEV int quad_bcast_i(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true); }
+// one dword of a butterfly stage: a = keepA ? x : partner(y), b = keepB ? y : partner(x).  `a` is written while x, y are still read
+// (early clobber); `b` is written by the last instruction and may reuse an input's register, so a stage needs one spare register, not eight.
+#define RT_QT_PAIR(PERM, X, Y, A, B)                                                                                               \
+    asm volatile("s_mov_b64 vcc, %[ka]\n\tv_cndmask_b32_dpp %[a], %[y], %[x], vcc quad_perm:" PERM " row_mask:0xf bank_mask:0xf\n\t" \
+                 "s_mov_b64 vcc, %[kb]\n\tv_cndmask_b32_dpp %[b], %[x], %[y], vcc quad_perm:" PERM " row_mask:0xf bank_mask:0xf"      \
+                 : [a] "=&v"(A), [b] "=v"(B) : [x] "v"(X), [y] "v"(Y), [ka] "s"(keepA), [kb] "s"(keepB) : "vcc")
+RT_DEV void quad_transpose(v4f &r0, v4f &r1, v4f &r2, v4f &r3) {
+    // in: r[k] of quad-lane q = piece q of record k; out: r[j] of quad-lane q = piece j of record q
+    v4f a0, a1, a2, a3;
+    {
+        const unsigned long long keepA = 0x5555555555555555ull, keepB = 0xAAAAAAAAAAAAAAAAull;   // lane bit 0 clear / set
+        asm volatile("s_nop 1");   // a DPP source written by a VALU instruction needs two wait states (not inserted inside inline asm)
+        RT_QT_PAIR("[1,0,3,2]", r0.x, r1.x, a0.x, a1.x); RT_QT_PAIR("[1,0,3,2]", r0.y, r1.y, a0.y, a1.y);
+        RT_QT_PAIR("[1,0,3,2]", r0.z, r1.z, a0.z, a1.z); RT_QT_PAIR("[1,0,3,2]", r0.w, r1.w, a0.w, a1.w);
+        RT_QT_PAIR("[1,0,3,2]", r2.x, r3.x, a2.x, a3.x); RT_QT_PAIR("[1,0,3,2]", r2.y, r3.y, a2.y, a3.y);
+        RT_QT_PAIR("[1,0,3,2]", r2.z, r3.z, a2.z, a3.z); RT_QT_PAIR("[1,0,3,2]", r2.w, r3.w, a2.w, a3.w);
+    }
+    {
+        const unsigned long long keepA = 0x3333333333333333ull, keepB = 0xCCCCCCCCCCCCCCCCull;   // lane bit 1 clear / set
+        RT_QT_PAIR("[2,3,0,1]", a0.x, a2.x, r0.x, r2.x); RT_QT_PAIR("[2,3,0,1]", a0.y, a2.y, r0.y, r2.y);
+        RT_QT_PAIR("[2,3,0,1]", a0.z, a2.z, r0.z, r2.z); RT_QT_PAIR("[2,3,0,1]", a0.w, a2.w, r0.w, r2.w);
+        RT_QT_PAIR("[2,3,0,1]", a1.x, a3.x, r1.x, r3.x); RT_QT_PAIR("[2,3,0,1]", a1.y, a3.y, r1.y, r3.y);
+        RT_QT_PAIR("[2,3,0,1]", a1.z, a3.z, r1.z, r3.z); RT_QT_PAIR("[2,3,0,1]", a1.w, a3.w, r1.w, r3.w);
+    }
+}
+
 // lane position of the n-th (0-based) set bit of m (n < popcount(m)): binary search over popcounts
 RT_DEV uint32_t nth_set(unsigned long long m, uint32_t n) {
     uint32_t pos = 0;
@@ -397,7 +429,7 @@ RT_DEV uint32_t quad_distinct(uint32_t key) {
 constexpr uint32_t kShards = 64, kShardStride = 32;   // cursor shards per trace launch, uint32 words between them (128 B)
 constexpr uint32_t kHeadWords = kShards * kShardStride;
 
-struct TraceTune { int refillMin; int minSearch; int chunk; int leafb; int skipTraversal; int quadRefill; };   // skipTraversal: diagnostic (RT_DEBUG_SKIP_TRAVERSAL)
+struct TraceTune { int refillMin; int minSearch; int chunk; int leafb; int skipTraversal; int quadRefill; int coop; };   // skipTraversal: diagnostic (RT_DEBUG_SKIP_TRAVERSAL)
 
 template <bool ANY> struct StackOf { typedef StackEntry type; };          // closest: {deferred child, its entry distance}
 template <> struct StackOf<true> { typedef uint32_t type; };              // any-hit: the pop-time cull never fires (tMax is constant)
@@ -406,7 +438,7 @@ template <> struct StackOf<true> { typedef uint32_t type; };              // any
 // with them the memory-level parallelism of these latency-bound loops -- follow from the scene's depth instead of from a few
 // compiled-in sizes (1 M triangles, depth 18: 4 / 5 workgroups per CU for closest- / any-hit instead of 3 / 4 with 24- and 36-entry stacks).
 extern __shared__ __align__(16) unsigned char rt_dyn_lds[];
-template <class Src, bool ANY, int LEAFB, bool STATS = false>
+template <class Src, bool ANY, int LEAFB, bool STATS = false, bool COOP = false>
 __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, const float4 *__restrict__ wnodes, const float4 *__restrict__ tris, Src src,
                                                 uint32_t *head, unsigned long long *tally, unsigned long long *gatherLoads, TraceTune tune,
                                                 int stackEntries, unsigned long long *stats = nullptr) {
@@ -577,6 +609,20 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
             if (__popcll(sm) < tune.minSearch && __ballot(active && (ANY ? leaf != 0 : ref < 0)) != 0ull) break;   // keep the leaf phase dense
             const unsigned long long tI_ = STATS ? clock64() : 0ull;
             if (STATS && lane == 0) { st_[3]++; st_[4] += (unsigned long long)__popcll(sm); }
+            // COOP (closest-hit, RT_COOP=1): the quad fetches its searching lanes' records together, then transposes (see quad_transpose)
+            v4f ca = {0, 0, 0, 0}, cb = ca, cc = ca, cd = ca;
+            if constexpr (COOP && !ANY) {
+                const uint32_t q = lane & 3u;
+                const int me = searching ? ref : -1;
+                const int i0 = quad_bcast_i<0x00>(me), i1 = quad_bcast_i<0x55>(me), i2 = quad_bcast_i<0xAA>(me), i3 = quad_bcast_i<0xFF>(me);
+                const v4f *nv = reinterpret_cast<const v4f *>(nodes) + q;
+                if (i0 >= 0) ca = nv[(size_t)i0 * 4];
+                if (i1 >= 0) cb = nv[(size_t)i1 * 4];
+                if (i2 >= 0) cc = nv[(size_t)i2 * 4];
+                if (i3 >= 0) cd = nv[(size_t)i3 * 4];
+                pin(ca); pin(cb); pin(cc); pin(cd);
+                quad_transpose(ca, cb, cc, cd);
+            }
             if (searching) {
                 if (STATS) { st_[0]++; const uint32_t dk = quad_distinct((uint32_t)ref), dw = wave_distinct((uint32_t)ref); if (lane == (uint32_t)(__ffsll((long long)sm) - 1)) { st_[12] += dk * (ANY ? 7u : 4u); st_[14] += dw * (ANY ? 7u : 4u); } }
                 gathers += ANY ? 7u : 4u;
@@ -613,8 +659,9 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
                 } else {
                     const float4 *nd = nodes + (size_t)ref * 4;
                     const v4f *ndv = reinterpret_cast<const v4f *>(nd);
-                    v4f a = ndv[0], b = ndv[1], c = ndv[2], d = ndv[3];
-                    pin(a); pin(b); pin(c); pin(d);
+                    v4f a, b, c, d;
+                    if constexpr (COOP) { a = ca; b = cb; c = cc; d = cd; }
+                    else { a = ndv[0]; b = ndv[1]; c = ndv[2]; d = ndv[3]; pin(a); pin(b); pin(c); pin(d); }
                     float tL, tR;
                     bool hitL = slab(ro, rdInv, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), tL) && tL <= tBest;
                     bool hitR = slab(ro, rdInv, mk3(c.x, c.y, c.z), mk3(d.x, d.y, d.z), tR) && tR <= tBest;
@@ -954,6 +1001,7 @@ void launch_trace(hipStream_t st, int cus, int gridPct, int depth, const DevFram
         hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), ldsBytes, st, fr, nodes, hs.pairs, src, head, tally, gatherLoads, tune, stack, stats);
     };
     if (stats) { if (tune.leafb >= 4) go(k_trace<Src, ANY, 4, true>); else go(k_trace<Src, ANY, 2, true>); }
+    else if (!ANY && tune.coop) go(k_trace<Src, ANY, 2, false, !ANY>);
     else       { if (tune.leafb >= 4) go(k_trace<Src, ANY, 4, false>); else go(k_trace<Src, ANY, 2, false>); }
 }
 
@@ -968,7 +1016,7 @@ struct RtWave {
     // ray-queue budget per frame lane; 288 GB of HBM make this cheap.  16 GB hold the queues of a whole batch of eight 1080p / 4 spp frames (7.4 M hits x
     // 2.1 KB) in ONE chunk: no hit-count read-back, half the launches (1.76-1.80 -> 1.68-1.72 ms per frame against 8 GB; profiles/r03_experiments.txt)
     size_t budgetBytes = (size_t)16 << 30;
-    TraceTune tune{32, 16, 0, 2, 0, 0};   // chunk 0 = run length chosen in the kernel from the queue size
+    TraceTune tune{32, 16, 0, 2, 0, 0, 0};   // chunk 0 = run length chosen in the kernel from the queue size
     // allocations
     size_t slotsCap = 0;      // per-frame arrays sized for this many pixel slots
     size_t chunkBytes = 0;    // bytes of the per-chunk arena
@@ -992,6 +1040,7 @@ RtWave *rt_wave_create(int cus) {
     if (const char *e = getenv("RT_MIN_SEARCH")) w->tune.minSearch = std::max(0, std::min(64, atoi(e)));
     if (const char *e = getenv("RT_CHUNKS_FROM_SLOTS")) w->chunksFromSlots = atoi(e) != 0;
     if (const char *e = getenv("RT_QUAD_REFILL")) w->tune.quadRefill = atoi(e) != 0;
+    if (const char *e = getenv("RT_COOP")) w->tune.coop = atoi(e);   // quad-cooperative node fetch of the closest-hit launches (measured option)
     return w;
 }
 void rt_wave_destroy(RtWave *w) {
@@ -1194,7 +1243,7 @@ void rt_wave_trace_closest_indexed(hipStream_t st, int cus, int treeDepth, const
                                    const uint32_t *count, const float4 *o, const float4 *d, float *outT, int *outTri, uint32_t *heads) {
     IndexedSrc q;
     q.idx = idx; q.count = count; q.o = o; q.d = d; q.outT = outT; q.outTri = outTri; q.n = 0;
-    TraceTune tune{32, 16, 0, 2, 0, 0};
+    TraceTune tune{32, 16, 0, 2, 0, 0, 0};
     launch_trace<IndexedSrc, false>(st, cus, 100, treeDepth, dFrame, hostScene, q, heads, nullptr, nullptr, tune, nullptr);
 }
 size_t rt_wave_head_words() { return kHeadWords; }

@@ -57,6 +57,9 @@ class FrameGatherer:
         self._ch = ch
         self.gathered = self.frame = None       # the pair of the most recent gather()
         self._wrapped = {}
+        self.timed = False                      # bench.py: device time of every gather (events on the gather's stream)
+        self._events = []
+        self._bytes = 0
 
     def _pair(self, sp):
         b = self._bufs.get(sp)
@@ -81,6 +84,11 @@ class FrameGatherer:
             stream = self._streams[sp] = torch.cuda.ExternalStream(sp, device=self.device)
         self.gathered, self.frame = self._pair(sp)
         with torch.cuda.stream(stream):
+            if self.timed:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record(stream)
+                self._events.append(ev)
+                self._bytes += self.block * (self.world - 1) if self.rank == 0 else self.block
             if self.world > 1 and self.host_staged:
                 h = loc.cpu()                    # waits for the frame on this stream
                 parts = [torch.empty_like(h) for _ in range(self.world)] if self.rank == 0 else None
@@ -100,9 +108,19 @@ class FrameGatherer:
                 if dst is None:
                     dst = self._wrapped[("hist", ptr)] = wrap_device_bytes(ptr, nbytes, self.device)
                 dist.all_gather_into_tensor(dst, col, group=self.group)
+            if self.timed:
+                self._events[-1][1].record(stream)
         if self.exchange_history and self.world > 1:
             self.ren.history_exchanged()       # the next frame's temporal resolve now waits for the all-gather too
         return self.frame
+
+    def timing(self):
+        """Device time of the gathers since `timed` was set (synchronises): {"ms", "gathers", "bytes"}; bytes = received on rank 0, sent elsewhere."""
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b in self._events)
+        out = {"ms": ms, "gathers": len(self._events), "bytes": self._bytes}
+        self._events, self._bytes = [], 0
+        return out
 
     def after(self, n_frames=1, last=False):
         """n_frames were rendered since the previous call (one rt_render_frames batch): gather the newest one if a gather_every boundary

@@ -50,6 +50,12 @@ def test_bench_line_contract():
         l1 = r["l1_gather"]
         assert l1 is not None and 0 < l1["merge_factor"] <= 1 and 0 < l1["frac"] <= 1        # a ceiling that is exceeded is not a ceiling
         assert abs(l1["frac"] - l1["achieved"] / l1["peak"]) < 1e-9 and l1["peak"] == 256 * 2.4
+    # the metric's RMSE leg: the last timed frame against the oracle, a window around the frame centre, whole history chain
+    pz = d["parity"]
+    assert pz["vs"] == "oracle" and pz["ok"] is True and pz["rmse"] < 1e-4 and pz["bit_diff"] == 0 and pz["outliers_gt_1e-2"] == 0
+    assert pz["frames_chained"] == 8 and pz["frame"] == 7 and set(pz["targets"]) == {"color", "motion", "gpos", "gnrm"}
+    x0, y0, x1, y1 = pz["window"]
+    assert (x1 - x0, y1 - y0) == (64, 32) and x0 <= 320 < x1 and y0 <= 180 < y1
     b = d["cpu_baseline"]
     assert b["kind"] == "port" and b["cores"] >= 1 and b["value"] > 0 and b["single_thread"]["cores"] == 1 and b["single_thread"]["value"] > 0
     assert "-O3 -march=native" in b["sample"]
@@ -76,6 +82,14 @@ def test_bench_self_launch_rehearsal_world_of_one():
     d = _bench(SMALL + ["--cpu-seconds", "0", "--no-default-camera", "--launch", "--force-gather", "--gpus", "1"])
     assert d["n_gpus"] == 1 and d["config"]["gather"]["path"].startswith("library-owned RCCL")
     assert d["config"]["batched_equals_frame_by_frame"] is True
+    # the self-diagnosing N-GPU block, here for a world of one over a real RCCL communicator
+    m = d["config"]["multi_gpu"]
+    assert m["rccl_world"] == [1] and m["rccl_rank"] == [0] and m["fallback"] == [False] and m["device"] == [0]
+    assert len(m["per_rank_ms"]["values"]) == 1 and 0 < m["per_rank_ms"]["max"] <= d["ms_per_step"] * 1.05 and abs(m["imbalance"] - 1.0) < 1e-9
+    assert m["gathers"] >= 1 and m["gather_ms_per_batch"] > 0 and m["gather_bytes"] == 0     # a world of one receives nothing
+    assert m["efficiency_vs_n1"] is None
+    # parity of the ASSEMBLED frame (the gather is inside the comparison)
+    assert d["parity"]["ok"] is True and d["parity"]["bit_diff"] == 0 and list(d["parity"]["targets"]) == ["color"]
 
 
 @pytest.mark.parametrize("ranks", [2, 3])
@@ -84,12 +98,20 @@ def test_bench_ranks_as_processes_on_one_gpu(ranks):
     the group is gloo and the gathers are staged through the host (RCCL refuses two ranks on one device).  What this covers that no
     one-process test can: the launch, RANK / WORLD_SIZE handling, barriers and max-over-ranks timing, counters summed over ranks, one gather
     per batch from N processes -- and rank 0 compares the assembled frame with the one a single context renders, bit for bit."""
-    d = _bench(SMALL + ["--cpu-seconds", "0", "--no-default-camera", "--no-diagnostics", "--gpus", str(ranks), "--rehearse-one-gpu"], timeout=900)
+    d = _bench(SMALL + ["--cpu-seconds", "0", "--no-default-camera", "--no-diagnostics", "--gpus", str(ranks), "--rehearse-one-gpu", "--n1-ms", "1.0"], timeout=900)
     assert d["n_gpus"] == ranks and d["scaling"] == "strong"
     c = d["config"]
     assert "gloo" in c["gather"]["path"] and "error" not in c["gather"]
     assert c["batched_equals_frame_by_frame"] is True        # every rank: its own tiles
     assert c["assembled_equals_single_rank"] is True
+    m = c["multi_gpu"]
+    assert len(m["per_rank_ms"]["values"]) == ranks and m["per_rank_ms"]["min"] > 0 and m["imbalance"] >= 1.0
+    assert m["rccl_world"] == [-1] * ranks and m["fallback"] == [False] * ranks       # the rehearsal runs over gloo, and says so
+    assert m["gathers"] >= 1 and m["gather_ms_per_batch"] > 0
+    tiles_other = m["gather_bytes"]                                                   # what rank 0 receives per gather: the other ranks' blocks
+    assert tiles_other > 0 and tiles_other % (256 * 8) == 0
+    assert abs(m["efficiency_vs_n1"] - 1.0 / (d["ms_per_step"] * ranks)) < 1e-9         # --n1-ms 1.0
+    assert d["parity"]["ok"] is True and d["parity"]["bit_diff"] == 0                   # the assembled frame against the oracle
     one = _bench(SMALL + ["--cpu-seconds", "0", "--no-default-camera", "--no-diagnostics"])
     assert c["rays_per_frame"] == one["config"]["rays_per_frame"]   # the ranks' reference-unit counters add up to the whole frame's
     assert c["hit_pixels"] == one["config"]["hit_pixels"]
