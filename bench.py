@@ -334,6 +334,7 @@ def main():
         traced = ren.traced_rays()
         info = ren.scene_info()
         batched_hash = color_hash(ren) if check else None
+        mem = ren.memory_info()
         comm = ren.comm_info() if multi else None
         if comm is not None:        # gathers of the timed region only
             comm.gathers -= comm0.gathers
@@ -395,7 +396,7 @@ def main():
             dist.all_reduce(tr, op=dist.ReduceOp.SUM)
         frames_all = max(int(tr[1].item()) // world, 1)
         traced_per_frame = int(tr[0].item()) // frames_all if traced.frames else 0
-        return {"seconds": float(tt.item()), "seconds_own": dt_own, "comm": comm, "gather_py": gather_py, "final_targets": final_targets, "frames_u": frames_u,
+        return {"seconds": float(tt.item()), "seconds_own": dt_own, "memory": mem, "comm": comm, "gather_py": gather_py, "final_targets": final_targets, "frames_u": frames_u,
                 "counters": total, "local_counters": cnt, "stages": stages,
                 "traced_per_frame": traced_per_frame, "traced": traced, "scene_info": info, "counted_frames": steps,
                 "batched_hash": batched_hash, "fbf_hash": fbf_hash, "fbf_ms": fbf_ms, "same": bool(same.item()) if check else None,
@@ -586,6 +587,12 @@ def main():
                                      "shadow rays of exactly zero weight are not traversed: rays_traversed_per_frame"},
         "roofline": roofline,
     }
+    mi = res["memory"]
+    out["config"]["hbm"] = {"in_use_GB": (mi.deviceTotalBytes - mi.deviceFreeBytes) / 1e9, "total_GB": mi.deviceTotalBytes / 1e9,
+                            "ray_queue_arenas_GB": mi.queueArenaBytes / 1e9, "ray_queue_arenas": mi.queueArenas, "frame_lanes": mi.lanes,
+                            "per_lane_frame_arrays_GB": mi.frameArrayBytes / 1e9, "hybrid_arena_GB": mi.hybridArenaBytes / 1e9,
+                            "what": "hipMemGetInfo on this rank's device right after the timed run (this context + the runtime's own allocations); "
+                                    "the ray-queue arenas are shared by the frame lanes (RT_ARENAS) and sized for one batch of frames each"}
     if st:
         out["stage_ms_per_frame"] = {k: v["ms"] / args.steps for k, v in st["stages"].items()}
         out["stage_ms_note"] = "HIP-event spans in the timed region; consecutive batches overlap on 3-4 streams, so spans add up to more than ms_per_step"

@@ -191,7 +191,12 @@ int rt_render_ray(RtContext *ctx, const RtRenderParams *params, const RtCamera *
  * Pipelines: staged (RT_PIPELINE_AUTO / _WAVEFRONT: shading passes that replay answered mesh queries and queue the open ones, persistent
  * closest-hit traversal launches in between; csrc/rt_hybrid.hip) or the megakernel (RT_PIPELINE_MEGAKERNEL); same frames bit for bit. */
 #define RT_SCENE_HYBRID 2
-typedef struct RtExtension { int32_t giBounces; int32_t reserved[3]; } RtExtension;
+/* envFilter: model of texture(uEnvMap, dir)'s LINEAR filter (src/render/cubemap.cpp:56-58 GL_RGB8, :95-102 LINEAR / CLAMP_TO_EDGE).
+ *   0 (default): bilinear weights from the fractional texel coordinates in exact fp32.
+ *   1: the texel coordinates u = s*N - 0.5, v = t*N - 0.5 are first rounded to nearest on a grid of 1/256 texel (8 fractional bits of
+ *      sub-texel precision, as GPU samplers filter RGB8), the weights (1-a)(1-b) ... then follow exactly; kept so that a capture from
+ *      a real GL driver can be compared under either model.  Same texels, same face selection, same clamping. */
+typedef struct RtExtension { int32_t giBounces; int32_t envFilter; int32_t reserved[2]; } RtExtension;
 int rt_set_extension(RtContext *ctx, const RtExtension *ext);   /* applies to the frames rendered after the call */
 
 /* `count` rt_render_ray calls with an unchanged camera and unchanged parameters, rendered through rt_render_frames (batched). */
@@ -285,6 +290,12 @@ typedef struct RtSceneInfo {
     uint64_t bytesNodes2, bytesNodes4, bytesPairs, bytesTris;
 } RtSceneInfo;
 int rt_get_scene_info(const RtContext *ctx, RtSceneInfo *out);
+
+/* Device memory behind the context: the ray-queue arenas of the wavefront pipeline (RtArenaPool: shared by the frame lanes), the
+ * per-lane frame arrays (candidate / hit lists, pre-resolve stash), the hybrid extension's arena, and the device's free / total bytes
+ * (hipMemGetInfo) -- bench.py reports them, so that the footprint of the timed mode is part of its line. */
+typedef struct RtMemoryInfo { uint64_t queueArenaBytes, frameArrayBytes, hybridArenaBytes, deviceFreeBytes, deviceTotalBytes; int32_t queueArenas, lanes; } RtMemoryInfo;
+int rt_get_memory_info(RtContext *ctx, RtMemoryInfo *out);
 
 /* Rays the wavefront pipeline actually traversed since the last reset (identical rays of the reference -- the SPP
  * copies of a primary ray, the per-sample copies of the AO rays -- are traced once; disk-light shadow rays whose

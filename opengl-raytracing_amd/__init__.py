@@ -142,8 +142,13 @@ class RtSceneInfo(_Struct):
                [(n, C.c_uint64) for n in ("bytesNodes2", "bytesNodes4", "bytesPairs", "bytesTris")]
 
 
+class RtMemoryInfo(_Struct):
+    _fields_ = [(n, C.c_uint64) for n in ("queueArenaBytes", "frameArrayBytes", "hybridArenaBytes", "deviceFreeBytes", "deviceTotalBytes")] + \
+               [(n, i32) for n in ("queueArenas", "lanes")]
+
+
 class RtExtension(_Struct):
-    _fields_ = _fields([("giBounces", i32), ("reserved", (i32, 3))])
+    _fields_ = _fields([("giBounces", i32), ("envFilter", i32), ("reserved", (i32, 2))])
 
 
 RT_SCENE_HYBRID = 2   # RtUniforms.useBVH: the analytic scene + the BVH mesh (extension, not in the reference)
@@ -205,6 +210,7 @@ SIGNATURES = {
     "rt_get_counters": (C.c_int, [C.c_void_p, C.POINTER(RtCounters)]),
     "rt_reset_counters": (C.c_int, [C.c_void_p]),
     "rt_get_scene_info": (C.c_int, [C.c_void_p, C.POINTER(RtSceneInfo)]),
+    "rt_get_memory_info": (C.c_int, [C.c_void_p, C.POINTER(RtMemoryInfo)]),
     "rt_get_traced_rays": (C.c_int, [C.c_void_p, C.POINTER(RtTracedRays), C.c_int]),
     "rt_enable_stage_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "rt_get_stage_times": (C.c_int, [C.c_void_p, C.POINTER(RtStageTimes)]),
@@ -520,9 +526,10 @@ class Renderer:
         self._check(lib().rt_render_ray(self._h, C.byref(params), C.byref(cam), int(use_bvh), int(show_motion),
                                         None if v is None else _fp(v), None if p is None else _fp(p)))
 
-    def set_extension(self, gi_bounces=1):
-        """EXTENSION (not in the reference): bounces of the analytic / hybrid GI path."""
-        e = RtExtension(giBounces=int(gi_bounces))
+    def set_extension(self, gi_bounces=1, env_filter=0):
+        """gi_bounces: EXTENSION (not in the reference), bounces of the analytic / hybrid GI path.  env_filter: cube-map filter model
+        (0 = bilinear weights in exact fp32, the default; 1 = texel coordinates rounded to 1/256 texel first)."""
+        e = RtExtension(giBounces=int(gi_bounces), envFilter=int(env_filter))
         self._check(lib().rt_set_extension(self._h, C.byref(e)))
 
     def render_ray_frames(self, params, cam, count, use_bvh=False, show_motion=False):
@@ -644,6 +651,11 @@ class Renderer:
     def scene_info(self) -> RtSceneInfo:
         i = RtSceneInfo()
         self._check(lib().rt_get_scene_info(self._h, C.byref(i)))
+        return i
+
+    def memory_info(self) -> RtMemoryInfo:
+        i = RtMemoryInfo()
+        self._check(lib().rt_get_memory_info(self._h, C.byref(i)))
         return i
 
     def traced_rays(self, reset=False) -> RtTracedRays:

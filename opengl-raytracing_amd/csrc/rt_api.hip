@@ -25,6 +25,7 @@ using namespace rtd;
 static thread_local std::string g_createError;
 
 #define RT_MAX_LANES 8
+constexpr int kDefaultArenas = 2;   // ray-queue arenas shared by the frame lanes (rt_wave.hpp RtArenaPool; measured in profiles/r04_experiments.txt)
 struct StageEvent { int stage; hipEvent_t a, b; };
 
 struct RtContext {
@@ -67,9 +68,11 @@ struct RtContext {
     void *dStaging = nullptr;
     size_t stagingBytes = 0;
     RtWave *wave[RT_MAX_LANES] = {};
+    RtArenaPool *arenaPool = nullptr;   // ray-queue arenas shared by the lanes' wavefront pipelines
     RtHybrid *hybrid[RT_MAX_LANES] = {};   // EXTENSION: staged hybrid pipeline, created on first use
     int cus = 256;
     int giBounces = 1;   // EXTENSION, rt_set_extension
+    int envFilter = 0;   // rt_set_extension: cube-map filter model (0 exact fp32 weights, 1 coordinates rounded to 1/256 texel)
     // tile-parallel exchange owned by the library (rt_comm.cpp): RCCL communicator + per-lane gather buffers on the gathering rank
     void *comm = nullptr;                               // ncclComm_t
     void *dGathered[RT_MAX_LANES][4] = {};              // [lane][target]: worldSize blocks, rank-major
@@ -218,6 +221,7 @@ DevScene make_dev_scene(const RtContext *c) {
     s.tris = c->dTris;
     s.env = c->dEnv;
     s.envSize = c->envSize;
+    s.envFilter = c->envFilter;
     s.rootRef = c->rootRef;
     s.rootRef4 = c->rootRef4;
     s.hasBVH = (c->nNodes > 0 && c->nTris > 0) ? 1 : 0;
@@ -356,7 +360,11 @@ int rt_create(const RtDeviceConfig *cfg, RtContext **out) {
     c->stream = c->lanes[0];
     (void)hipMemset(c->dCounters, 0, 16 * sizeof(unsigned long long));
     c->cus = prop.multiProcessorCount;
-    for (int i = 0; i < c->nLanes; ++i) c->wave[i] = rt_wave_create(prop.multiProcessorCount);
+    // ray-queue arenas: RT_ARENAS of them shared by the lanes (default below; = lanes: one each, as in rounds 1-3)
+    int arenas = std::min(c->nLanes, kDefaultArenas);
+    if (const char *e = getenv("RT_ARENAS")) arenas = std::max(1, std::min(atoi(e), c->nLanes));
+    c->arenaPool = rt_arena_pool_create(arenas);
+    for (int i = 0; i < c->nLanes; ++i) c->wave[i] = rt_wave_create(prop.multiProcessorCount, c->arenaPool, i);
     c->lastStream = c->stream;
     int rc = rt_upload_env(c, nullptr, 0, 0);   // dummy cube map like Application::initState (application.cpp:281)
     if (rc != RT_OK) { g_createError = c->err; rt_destroy(c); return rc; }
@@ -371,6 +379,7 @@ void rt_destroy(RtContext *c) {
     (void)rt_comm_destroy(c);
     free_targets(c);
     for (int i = 0; i < RT_MAX_LANES; ++i) { if (c->hybrid[i]) rt_hybrid_destroy(c->hybrid[i]); if (c->wave[i]) rt_wave_destroy(c->wave[i]); if (c->dFrame[i]) (void)hipFree(c->dFrame[i]); if (c->evDone[i]) (void)hipEventDestroy(c->evDone[i]); }
+    rt_arena_pool_destroy(c->arenaPool);
     for (int i = 0; i < RT_MAX_LANES; ++i) if (c->lanes[i]) (void)hipStreamDestroy(c->lanes[i]);   // c->stream is lanes[0]
     if (c->dWNodes) (void)hipFree(c->dWNodes);
     if (c->dW4) (void)hipFree(c->dW4);
@@ -891,7 +900,9 @@ int rt_render_ray(RtContext *c, const RtRenderParams *params, const RtCamera *ca
 int rt_set_extension(RtContext *c, const RtExtension *ext) {
     if (!c || !ext) return RT_ERR_INVALID;
     if (ext->giBounces < 1 || ext->giBounces > 8) return fail(c, RT_ERR_INVALID, "rt_set_extension: giBounces = %d (1..8)", ext->giBounces);
+    if (ext->envFilter != 0 && ext->envFilter != 1) return fail(c, RT_ERR_INVALID, "rt_set_extension: envFilter = %d (0 or 1)", ext->envFilter);
     c->giBounces = ext->giBounces;
+    c->envFilter = ext->envFilter;
     return RT_OK;
 }
 
@@ -1093,6 +1104,20 @@ int rt_get_scene_info(const RtContext *c, RtSceneInfo *out) {
     out->bytesNodes4 = (uint64_t)c->nWide4 * 128;
     out->bytesPairs = (uint64_t)c->nPairs * 80;
     out->bytesTris = (uint64_t)c->nTris * 48;
+    return RT_OK;
+}
+
+int rt_get_memory_info(RtContext *c, RtMemoryInfo *out) {
+    if (!c || !out) return RT_ERR_INVALID;
+    std::memset(out, 0, sizeof *out);
+    (void)hipSetDevice(c->cfg.device);
+    out->queueArenaBytes = rt_arena_pool_bytes(c->arenaPool);
+    out->queueArenas = rt_arena_pool_count(c->arenaPool);
+    out->lanes = c->nLanes;
+    for (int i = 0; i < c->nLanes; ++i) { out->frameArrayBytes += rt_wave_frame_bytes(c->wave[i]); out->hybridArenaBytes += rt_hybrid_arena_bytes(c->hybrid[i]); }
+    size_t fr = 0, tot = 0;
+    HIP_TRY(c, hipMemGetInfo(&fr, &tot));
+    out->deviceFreeBytes = fr; out->deviceTotalBytes = tot;
     return RT_OK;
 }
 

@@ -97,9 +97,8 @@ __device__ __noinline__ bool traceScene(const Frag &F, V3 ro, V3 rd, bool includ
         if (sc.hasBVH && slab(ro, rdInv, ld3(sc.rootMin), ld3(sc.rootMax), tmin) && !(tmin > u.inf)) {
             const uint32_t q = R.q++;
             if (q < R.known) {
-                const size_t a = (size_t)q * R.stride + R.thread;
-                const int tri = R.logTri[a];
-                const float t = R.logT[a];
+                const int tri = R.logTri[q];
+                const float t = R.logT[q];
                 if (tri >= 0 && t < hit.t) {
                     hit.t = t;
                     hit.p = ro + rd * t;
@@ -112,7 +111,7 @@ __device__ __noinline__ bool traceScene(const Frag &F, V3 ro, V3 rd, bool includ
                 // the thread does after it is right exactly if that answer, and every later speculated one, turns out to be a miss.
                 R.pending++;
                 if (q < R.qmax) {
-                    const size_t a = (size_t)q * R.stride + R.thread;
+                    const size_t a = (size_t)q * 256u + R.slot;
                     R.o[a] = make_float4(ro.x, ro.y, ro.z, hit.t);   // .w: the analytic scene's hit distance (uINF: none) -- a mesh hit behind it changes nothing
                     R.d[a] = make_float4(rd.x, rd.y, rd.z, geometric ? 1.0f : 0.0f);   // .w: later rays are built from this hit
                     R.recEnd = q + 1u;

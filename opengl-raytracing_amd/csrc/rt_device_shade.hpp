@@ -34,6 +34,7 @@ struct DevScene {
     const float4 *tris;
     const uchar4 *env;
     int envSize;
+    int envFilter;   // 0: bilinear weights in exact fp32 (default); 1: texel coordinates rounded to 1/256 of a texel first (RtExtension.envFilter)
     int rootRef;
     int rootRef4;
     int rootRefW;
@@ -267,16 +268,18 @@ RT_DEV V3 tri_normal(const DevScene &sc, int tri) {
 // EXTENSION (hybrid scene, staged): replay state of one (pixel, sample) thread of rt_hybrid.hip.  The analytic shading code asks for mesh
 // hits through ONE function (traceScene); staged, that function answers from a log of earlier passes and records what it cannot answer yet
 // into a ray queue that a persistent traversal launch then traces.  Queries are numbered in program order (only those whose ray meets
-// the mesh's root box count), entry q of thread i lives at [q * stride + i] of every array.
+// the mesh's root box count).  Round 4: the log is the thread's own contiguous block of a bump arena (entry q at logT[q] / logTri[q]), and an
+// open query is written to the WORKGROUP's staging area (entry q of thread `slot` at [q * 256 + slot]), from which the end of the shading pass
+// packs what was really recorded into dense arrays -- memory follows the recorded queries, not qmax x threads.
 struct Replay {
     uint32_t q = 0;           // queries met so far in this pass
     uint32_t known = 0;       // queries answered by earlier passes
     uint32_t recEnd = 0;      // one past the last query recorded in this pass
     uint32_t pending = 0;     // queries without an answer met in this pass: recorded, and answered "no hit" on speculation
     bool overflow = false;    // more than qmax queries
-    uint32_t thread = 0, stride = 0, qmax = 0;
-    float4 *o = nullptr, *d = nullptr;
-    const float *logT = nullptr;
+    uint32_t slot = 0, qmax = 0;
+    float4 *o = nullptr, *d = nullptr;   // staging area of this thread's workgroup
+    const float *logT = nullptr;         // this thread's log
     const int *logTri = nullptr;
 };
 
@@ -310,6 +313,10 @@ RT_DEV V3 texture_cube(const DevScene &sc, V3 d, Work &w) {
     float t = 0.5f * (tcv / ma + 1.0f);
     const int N = sc.envSize;
     float fu = s * (float)N - 0.5f, fv = t * (float)N - 0.5f;
+    if (sc.envFilter == 1) {   // fixed-point texel coordinates, 8 fractional bits, round to nearest (see RtExtension.envFilter)
+        fu = __builtin_floorf(fu * 256.0f + 0.5f) * 0.00390625f;
+        fv = __builtin_floorf(fv * 256.0f + 0.5f) * 0.00390625f;
+    }
     float flu = __builtin_floorf(fu), flv = __builtin_floorf(fv);
     float a = fu - flu, b = fv - flv;
     int i0 = (int)flu, j0 = (int)flv;

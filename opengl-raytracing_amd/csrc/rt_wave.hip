@@ -33,6 +33,7 @@
 #include <cstdio>
 #include <map>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "../../include/rt_mi355.h"
@@ -64,6 +65,7 @@ struct WaveBuf {
     float4 *sh2O, *sh2D;     // shadow queue 2: 6 slots x (CH*SPP), entries compacted over the (hit, sample) pairs whose bounce hit
     uint8_t *occ2;
     int *giPos;              // per (sample, hit): entry in queue 2, -1 when the bounce ray missed or was not cast
+    int *giPerm;             // RT_BIN_GI=1 (experiment, round 4): per (sample, hit) the bounce queue entry its ray was sorted to; null = entry (sample, hit) itself
     // per frame, per pixel slot: everything the frame produced BEFORE the temporal resolve (the only history-dependent step)
     float4 *pendC;           // curr.rgb (frame average, fp32), motion.x
     float *pendMy;           // motion.y
@@ -71,6 +73,11 @@ struct WaveBuf {
     uint32_t CH;             // chunk capacity (hits)
     int A;                   // AO rays per hit (0 when AO is off)
     int SPP;
+    // slot of shadow queue 1 for ray k of sample s: A AO slots, then the four disk-light rays of every sample, then ONE sun and ONE point-light
+    // slot per hit -- those two rays do not depend on the sample (rt_lighting.glsl:114-214), sample 0 traces them and the others reuse its answer,
+    // so samples > 0 own no slot for them (round 4: 22 instead of 28 slots per hit at 4 spp)
+    __device__ __forceinline__ uint32_t gi_entry(int s, uint32_t j) const { const uint32_t a = (uint32_t)s * CH + j; return giPerm ? (uint32_t)giPerm[a] : a; }
+    __device__ __forceinline__ uint32_t sh1_slot(int s, int k) const { return (uint32_t)(k < 4 ? A + s * 4 + k : A + 4 * SPP + (k - 4)); }
 };
 
 namespace {
@@ -345,6 +352,31 @@ struct IndexedSrc {
     RT_DEV void store_any(uint32_t, bool) const {}
 };
 
+// A dense array of ray records (rt_hybrid.hip, round 4): ray r is the record o[r] / d[r]; its answer goes to outT / outTri at dst[r] (the asking
+// thread's log entry).  The list length is read on the device and clipped to the array's capacity (an overflowing pass is redone by the host).
+struct CompactSrc {
+    const float4 *o, *d;
+    const uint32_t *dst;
+    const uint32_t *count;
+    const uint32_t *flags;   // bits 2 | 4: a pass outgrew its arrays -- the queue is incomplete and must not be traced
+    uint32_t cap;
+    float *outT;
+    int *outTri;
+    uint32_t n;
+    RT_DEV void prepare() { n = (*flags & 6u) ? 0u : min(*count, cap); }
+    RT_DEV uint32_t size() const { return n; }
+    struct Payload { uint32_t a; };
+    RT_DEV float probe(uint32_t r, Payload &p) const { p.a = r; return 1.0f; }
+    RT_DEV static Payload route(const Payload &p, int e) { Payload q; q.a = (uint32_t)__shfl((int)p.a, e, 64); return q; }
+    RT_DEV void take(uint32_t, const Payload &p, V3 &ro, V3 &rd, uint32_t &token) const {
+        token = dst[p.a];
+        const float4 oo = o[p.a], dd = d[p.a];
+        ro = f4xyz(oo); rd = f4xyz(dd);
+    }
+    RT_DEV void store_closest(uint32_t a, float t, int tri) const { outT[a] = t; outTri[a] = tri; }
+    RT_DEV void store_any(uint32_t, bool) const {}
+};
+
 // hipcc sinks loads into the branches that first use them (e.g. a triangle's v0 behind the determinant test), which turns
 // one gather round trip into two or three dependent ones.  pin() makes a loaded record "used" right after the loads were
 // issued, so the whole group is in flight together.
@@ -429,7 +461,7 @@ RT_DEV uint32_t quad_distinct(uint32_t key) {
 constexpr uint32_t kShards = 64, kShardStride = 32;   // cursor shards per trace launch, uint32 words between them (128 B)
 constexpr uint32_t kHeadWords = kShards * kShardStride;
 
-struct TraceTune { int refillMin; int minSearch; int chunk; int leafb; int skipTraversal; int quadRefill; int coop; };   // skipTraversal: diagnostic (RT_DEBUG_SKIP_TRAVERSAL)
+struct TraceTune { int refillMin; int minSearch; int chunk; int leafb; int skipTraversal; int quadRefill; int coop; int leafbClosest; };   // skipTraversal: diagnostic (RT_DEBUG_SKIP_TRAVERSAL)
 
 template <bool ANY> struct StackOf { typedef StackEntry type; };          // closest: {deferred child, its entry distance}
 template <> struct StackOf<true> { typedef uint32_t type; };              // any-hit: the pop-time cull never fires (tMax is constant)
@@ -438,8 +470,10 @@ template <> struct StackOf<true> { typedef uint32_t type; };              // any
 // with them the memory-level parallelism of these latency-bound loops -- follow from the scene's depth instead of from a few
 // compiled-in sizes (1 M triangles, depth 18: 4 / 5 workgroups per CU for closest- / any-hit instead of 3 / 4 with 24- and 36-entry stacks).
 extern __shared__ __align__(16) unsigned char rt_dyn_lds[];
+// Register budget: the closest-hit launches run five workgroups per CU (their 8-byte stack entries fill the LDS first), so their kernels may use
+// up to 96 VGPRs (five waves per SIMD) but not more; the diagnostic builds are unconstrained.
 template <class Src, bool ANY, int LEAFB, bool STATS = false, bool COOP = false>
-__global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, const float4 *__restrict__ wnodes, const float4 *__restrict__ tris, Src src,
+__global__ __launch_bounds__(256, (!STATS && !ANY) ? 5 : 1) void k_trace(const DevFrame *__restrict__ fr, const float4 *__restrict__ wnodes, const float4 *__restrict__ tris, Src src,
                                                 uint32_t *head, unsigned long long *tally, unsigned long long *gatherLoads, TraceTune tune,
                                                 int stackEntries, unsigned long long *stats = nullptr) {
     // STATS (diagnostic build only, RT_TRACE_STATS=1): [0] inner-node visits [1] leaf visits [2] triangle tests [3] inner-phase wave
@@ -693,37 +727,42 @@ __global__ __launch_bounds__(256) void k_trace(const DevFrame *__restrict__ fr, 
             // Two triangles of a leaf share one 80-byte record (5 gather loads instead of 6).  Records of a leaf are contiguous:
             // fetch LEAFB/2 of them at a time so that the gather round trips of one group overlap (the array is padded, so no
             // bounds branch); test in leaf order.
-            constexpr int NP = LEAFB / 2;
-            // full groups of LEAFB triangles (LEAFB/2 pair records of 5 loads each) ...
-            const int nFull = (LEAFB == 2) ? (count & ~1) : count;   // LEAFB == 2: an odd last triangle is left to the 3-load tail below
-            for (int i = 0; i < nFull && !done; i += LEAFB) {
+            // LEAFB == 4 (closest-hit launches, round 4): groups of FOUR triangles (two records, 10 loads in flight) while at least four are left,
+            // then pairs, then the odd tail -- a 5-triangle leaf is two dependent round trips instead of three.  The closest-hit launches are held
+            // to five workgroups per CU by their LDS stacks, so the 96 registers of this form cost them no occupancy (the any-hit launch would
+            // drop from six to five waves per SIMD: it keeps LEAFB == 2).
+            auto group = [&](auto npc, int i) {
+                constexpr int NPG = decltype(npc)::value;
                 const float4 *t = sc.tris + (size_t)(first + (i >> 1)) * 5;
-                gathers += 5u * NP;
-                if (STATS) { const unsigned long long am = __ballot(1); const uint32_t dk = quad_distinct((uint32_t)(first + (i >> 1))), dw = wave_distinct((uint32_t)(first + (i >> 1))); if (lane == (uint32_t)(__ffsll((long long)am) - 1)) { st_[13] += dk * 5u * NP; st_[15] += dw * 5u * NP; } }
+                gathers += 5u * NPG;
+                if (STATS) { const unsigned long long am = __ballot(1); const uint32_t dk = quad_distinct((uint32_t)(first + (i >> 1))), dw = wave_distinct((uint32_t)(first + (i >> 1))); if (lane == (uint32_t)(__ffsll((long long)am) - 1)) { st_[13] += dk * 5u * NPG; st_[15] += dw * 5u * NPG; } }
                 const v4f *tv = reinterpret_cast<const v4f *>(t);
-                v4f rec[NP][5];
+                v4f rec[NPG][5];
 #pragma unroll
-                for (int k = 0; k < NP; ++k) { rec[k][0] = tv[k * 5 + 0]; rec[k][1] = tv[k * 5 + 1]; rec[k][2] = tv[k * 5 + 2]; rec[k][3] = tv[k * 5 + 3]; rec[k][4] = tv[k * 5 + 4]; }
+                for (int k = 0; k < NPG; ++k) { rec[k][0] = tv[k * 5 + 0]; rec[k][1] = tv[k * 5 + 1]; rec[k][2] = tv[k * 5 + 2]; rec[k][3] = tv[k * 5 + 3]; rec[k][4] = tv[k * 5 + 4]; }
 #pragma unroll
-                for (int k = 0; k < NP; ++k) { pin(rec[k][0]); pin(rec[k][1]); pin(rec[k][2]); pin(rec[k][3]); pin(rec[k][4]); }
+                for (int k = 0; k < NPG; ++k) { pin(rec[k][0]); pin(rec[k][1]); pin(rec[k][2]); pin(rec[k][3]); pin(rec[k][4]); }
 #pragma unroll
-                for (int k = 0; k < LEAFB; ++k) {
+                for (int k = 0; k < 2 * NPG; ++k) {
                     const v4f &r0 = rec[k >> 1][0], &r1 = rec[k >> 1][1], &r2 = rec[k >> 1][2], &r3 = rec[k >> 1][3], &r4 = rec[k >> 1][4];
                     const V3 v0 = (k & 1) ? mk3(r2.y, r2.z, r2.w) : mk3(r0.x, r0.y, r0.z);
                     const V3 e1 = (k & 1) ? mk3(r3.x, r3.y, r3.z) : mk3(r0.w, r1.x, r1.y);
                     const V3 e2 = (k & 1) ? mk3(r3.w, r4.x, r4.y) : mk3(r1.z, r1.w, r2.x);
                     float tt;
-                    if (STATS && !done && i + k < count) st_[2]++;
-                    if (!done && i + k < count && tri_hit(ro, rd, v0, e1, e2, eps, tBest, tt)) {
+                    if (STATS && !done) st_[2]++;
+                    if (!done && tri_hit(ro, rd, v0, e1, e2, eps, tBest, tt)) {
                         if (ANY) done = true;
                         else { tBest = tt; triBest = (int)f2u(r4.z) + (k & 1); }
                     }
                 }
-            }
+            };
+            int i = 0;
+            if constexpr (LEAFB >= 4) for (; i + 4 <= count && !done; i += 4) group(std::integral_constant<int, 2>{}, i);
+            for (; i + 2 <= count && !done; i += 2) group(std::integral_constant<int, 1>{}, i);
             // ... then the odd last triangle of the leaf: its record holds ONE triangle, whose nine floats (and, for closest-hit rays, its
             // index, repeated in the otherwise unused tenth float) sit in the first three 16-byte pieces: 3 gather loads instead of 5
             // (every leaf of the bench mesh has 5 triangles: 13 loads per leaf visit instead of 15).
-            if (LEAFB == 2 && (count & 1) && !done) {
+            if ((count & 1) && !done) {
                 const float4 *t = sc.tris + (size_t)(first + (count >> 1)) * 5;
                 gathers += 3u;
                 if (STATS) { const unsigned long long am = __ballot(1); const uint32_t dk = quad_distinct((uint32_t)(first + (count >> 1))), dw = wave_distinct((uint32_t)(first + (count >> 1))); if (lane == (uint32_t)(__ffsll((long long)am) - 1)) { st_[13] += dk * 3u; st_[15] += dw * 3u; } st_[2]++; }
@@ -808,23 +847,25 @@ struct GenDirectTracer {   // records first-generation rays of (hit j, sample s)
     uint32_t shadowMask;
     bool giCast;
     RT_DEV bool shadow(int, int k, V3 ro, V3 rd, float tMax, bool matters) {
-        uint32_t a = (uint32_t)(wb.A + s * 6 + k) * wb.CH + j;
         shadowMask |= 1u << k;
         // sun (k = 4) and point-light (k = 5) rays start at hp + N*e / hp + L*e towards a fixed light: the same ray for every
         // sample of the pixel (rt_lighting.glsl:114-214 never look at the seed) -- sample 0 traces it, the others reuse its answer
-        if (k >= 4 && s > 0) { wb.shT[a] = -1.0f; return false; }
+        if (k >= 4 && s > 0) return false;
+        uint32_t a = wb.sh1_slot(s, k) * wb.CH + j;
         if (!matters) { wb.shT[a] = -1.0f; return false; }   // dead ray: its answer is multiplied by zero
         wb.shT[a] = fmaxr(tMax, 0.0f);
         wb.shO[a] = mkf4(ro, 0.0f);
         wb.shD[a] = mkf4(rd, 0.0f);
         return false;
     }
+    V3 giRo, giRd;   // RT_BIN_GI: the bounce ray is kept here and written by the workgroup's sort (k_gen_direct)
     RT_DEV int gi(V3 ro, V3 rd, V3 &, V3 &) {
+        giCast = true;
+        if (wb.giPerm) { giRo = ro; giRd = rd; return -1; }
         uint32_t a = (uint32_t)s * wb.CH + j;
         wb.giL[a] = 1.0f;
         wb.giO[a] = mkf4(ro, 0.0f);
         wb.giD[a] = mkf4(rd, 0.0f);
-        giCast = true;
         return -1;
     }
     RT_DEV bool ao(int i, V3 org, V3 dir, float radius) {
@@ -854,7 +895,7 @@ struct GenGiTracer {       // reads the bounce result, records the shadow rays a
         return false;
     }
     RT_DEV int gi(V3 ro, V3 rd, V3 &hp, V3 &hn) {
-        uint32_t a = (uint32_t)s * wb.CH + j;
+        uint32_t a = wb.gi_entry(s, j);
         int tri = wb.giTri[a];
         if (tri < 0) return 0;
         hp = ro + rd * wb.giT[a];
@@ -870,11 +911,11 @@ struct CombineTracer {     // reads everything
     int s;
     RT_DEV bool shadow(int seg, int k, V3, V3, float, bool matters) {
         if (!matters) return false;
-        if (seg == SEG_DIRECT) return wb.occ1[(uint32_t)(wb.A + (k >= 4 ? 0 : s) * 6 + k) * wb.CH + j] != 0;   // sun / point: sample 0's ray
+        if (seg == SEG_DIRECT) return wb.occ1[wb.sh1_slot(k >= 4 ? 0 : s, k) * wb.CH + j] != 0;   // sun / point: sample 0's ray
         return wb.occ2[(uint32_t)k * (wb.CH * (uint32_t)wb.SPP) + (uint32_t)wb.giPos[(uint32_t)s * wb.CH + j]] != 0;
     }
     RT_DEV int gi(V3 ro, V3 rd, V3 &hp, V3 &hn) {
-        uint32_t a = (uint32_t)s * wb.CH + j;
+        uint32_t a = wb.gi_entry(s, j);
         int tri = wb.giTri[a];
         if (tri < 0) return 0;
         hp = ro + rd * wb.giT[a];
@@ -906,21 +947,52 @@ __global__ __launch_bounds__(256) void k_gen_direct(const DevFrame *__restrict__
     const RtUniforms &u = fr->u;
     const uint32_t live = chunk_live(wb, c0);
     const uint32_t tid = blockIdx.x * 256 + threadIdx.x;
-    if (live == 0 || tid >= live * (uint32_t)wb.SPP) return;
-    const int s = (int)(tid / live);
-    const uint32_t j = tid % live;
-    HitCtx c = load_hit(fr, wb.hits[c0 + j]);
-    const int SPP = max(u.spp, 1);
-    const int seed = (int)((uint32_t)c.F.frameIndex * (uint32_t)SPP + (uint32_t)s);
+    const bool mine = live != 0 && tid < live * (uint32_t)wb.SPP;
+    if (!mine && (!wb.giPerm || live == 0 || blockIdx.x * 256u >= live * (uint32_t)wb.SPP)) return;   // (the sort below needs whole workgroups)
+    const int s = mine ? (int)(tid / live) : 0;
+    const uint32_t j = mine ? tid % live : 0;
     GenDirectTracer tr;
     tr.wb = wb; tr.j = j; tr.s = s; tr.shadowMask = 0; tr.giCast = false;
-    (void)directLightBVH(tr, c.F, SEG_DIRECT, c.hp, c.hn, seed, -c.dir);
-    for (int k = 4; k < 6; ++k)   // sun / point rays are conditional (rt_lighting.glsl:123,194)
-        if (!(tr.shadowMask & (1u << k))) wb.shT[(uint32_t)(wb.A + s * 6 + k) * wb.CH + j] = -1.0f;
-    Work w;
-    if (u.enableGI == 1) (void)oneBounceGIBVH<GenDirectTracer, false>(tr, c.F, c.hp, c.hn, c.F.frameIndex, seed, w);
-    if (!tr.giCast) wb.giL[(uint32_t)s * wb.CH + j] = -1.0f;
-    if (s == 0 && wb.A > 0) (void)computeAO_BVH(tr, c.F, c.hp, c.hn, c.F.frameIndex);
+    tr.giRo = mk3(0.0f); tr.giRd = mk3(0.0f);
+    if (mine) {
+        HitCtx c = load_hit(fr, wb.hits[c0 + j]);
+        const int SPP = max(u.spp, 1);
+        const int seed = (int)((uint32_t)c.F.frameIndex * (uint32_t)SPP + (uint32_t)s);
+        (void)directLightBVH(tr, c.F, SEG_DIRECT, c.hp, c.hn, seed, -c.dir);
+        if (s == 0)
+            for (int k = 4; k < 6; ++k)   // sun / point rays are conditional (rt_lighting.glsl:123,194)
+                if (!(tr.shadowMask & (1u << k))) wb.shT[wb.sh1_slot(0, k) * wb.CH + j] = -1.0f;
+        Work w;
+        if (u.enableGI == 1) (void)oneBounceGIBVH<GenDirectTracer, false>(tr, c.F, c.hp, c.hn, c.F.frameIndex, seed, w);
+        if (!tr.giCast && !wb.giPerm) wb.giL[(uint32_t)s * wb.CH + j] = -1.0f;
+        if (s == 0 && wb.A > 0) (void)computeAO_BVH(tr, c.F, c.hp, c.hn, c.F.frameIndex);
+    }
+    if (wb.giPerm) {
+        // EXPERIMENT (RT_BIN_GI=1): the workgroup's 256 bounce rays -- 256 consecutive hits of one sample, i.e. neighbouring
+        // pixels -- are written sorted by direction (octant, then two bits of each |component|), so that quad-mates of the bounce launch start out
+        // with like rays.  Results stay addressable through giPerm; nothing else changes, frames are bit-identical.
+        __shared__ uint32_t sKey[256], sAddr[256];
+        uint32_t key = 0xffffffffu;
+        if (mine && tr.giCast) {
+            const V3 d = tr.giRd;
+            const uint32_t oct = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
+            auto q2 = [](float v) { return (uint32_t)min(3, (int)(__builtin_fabsf(v) * 4.0f)); };
+            key = (oct << 6) | (q2(d.x) << 4) | (q2(d.y) << 2) | q2(d.z);
+        }
+        sKey[threadIdx.x] = key;
+        sAddr[threadIdx.x] = mine ? (uint32_t)s * wb.CH + j : 0xffffffffu;
+        __syncthreads();
+        uint32_t rank = 0;
+        for (uint32_t i = 0; i < 256u; ++i) { const uint32_t ki = sKey[i]; rank += (ki < key || (ki == key && i < threadIdx.x)) ? 1u : 0u; }
+        // thread t's record goes to the address of the rank-th thread; threads outside the list (not mine) have the largest keys AND the largest
+        // thread indices, so the first `mine` ranks map onto the `mine` addresses
+        const uint32_t target = sAddr[rank];
+        if (mine) {
+            wb.giPerm[(uint32_t)s * wb.CH + j] = (int)target;
+            if (tr.giCast) { wb.giL[target] = 1.0f; wb.giO[target] = mkf4(tr.giRo, 0.0f); wb.giD[target] = mkf4(tr.giRd, 0.0f); }
+            else wb.giL[target] = -1.0f;
+        }
+    }
 }
 
 // ---- stage: gen_gi -------------------------------------------------------------------------------
@@ -932,7 +1004,8 @@ __global__ __launch_bounds__(256) void k_gen_gi(const DevFrame *__restrict__ fr,
     const int s = mine ? (int)(tid / live) : 0;
     const uint32_t j = mine ? tid % live : 0;
     const uint32_t a = (uint32_t)s * wb.CH + j;
-    const bool bounced = mine && wb.giL[a] >= 0.0f && wb.giTri[a] >= 0;
+    const uint32_t ae = mine ? wb.gi_entry(s, j) : 0u;   // where this (hit, sample)'s bounce ray and its answer are
+    const bool bounced = mine && wb.giL[ae] >= 0.0f && wb.giTri[ae] >= 0;
     const uint32_t pos = block_append(bounced, giCount);   // compact the (hit, sample) pairs that need second-generation rays
     if (!mine) return;
     wb.giPos[a] = bounced ? (int)pos : -1;
@@ -991,8 +1064,11 @@ void launch_trace(hipStream_t st, int cus, int gridPct, int depth, const DevFram
     const size_t ldsBytes = (size_t)256 * stack * (ANY ? 4 : 8);
     const float4 *nodes = ANY ? hs.w4 : hs.wnodesW;
     auto go = [&](auto kernel) {
-        thread_local std::map<std::pair<const void *, size_t>, int> occ;   // the runtime's answer per (kernel, LDS bytes)
-        int &perCU = occ[{(const void *)kernel, ldsBytes}];
+        // the runtime's answer per (device, kernel, LDS bytes): a process may hold contexts on devices of different shapes
+        thread_local std::map<std::tuple<int, const void *, size_t>, int> occ;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        int &perCU = occ[std::make_tuple(dev, (const void *)kernel, ldsBytes)];
         if (perCU == 0) {
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kernel, 256, ldsBytes) != hipSuccess || perCU < 1) perCU = 1;
             perCU = std::min(perCU, 8);
@@ -1000,9 +1076,10 @@ void launch_trace(hipStream_t st, int cus, int gridPct, int depth, const DevFram
         const unsigned blocks = (unsigned)std::max(8, cus * perCU * gridPct / 100);
         hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), ldsBytes, st, fr, nodes, hs.pairs, src, head, tally, gatherLoads, tune, stack, stats);
     };
-    if (stats) { if (tune.leafb >= 4) go(k_trace<Src, ANY, 4, true>); else go(k_trace<Src, ANY, 2, true>); }
+    const int leafb = ANY ? tune.leafb : tune.leafbClosest;
+    if (stats) { if (leafb >= 4) go(k_trace<Src, ANY, 4, true>); else go(k_trace<Src, ANY, 2, true>); }
     else if (!ANY && tune.coop) go(k_trace<Src, ANY, 2, false, !ANY>);
-    else       { if (tune.leafb >= 4) go(k_trace<Src, ANY, 4, false>); else go(k_trace<Src, ANY, 2, false>); }
+    else       { if (leafb >= 4) go(k_trace<Src, ANY, 4, false>); else go(k_trace<Src, ANY, 2, false>); }
 }
 
 }  // namespace
@@ -1010,43 +1087,76 @@ void launch_trace(hipStream_t st, int cus, int gridPct, int depth, const DevFram
 // -------------------------------------------------------------------------------------------------
 constexpr int kMinLaunches = 256;   // trace launches per frame (1 + 3 per chunk) the cursor table starts with; grown on demand
 
+#ifndef RT_MAX_LANES
+#define RT_MAX_LANES 8
+#endif
+struct RtArenaPool {
+    int n = 0;
+    void *mem[RT_MAX_LANES] = {};
+    size_t bytes[RT_MAX_LANES] = {};
+    hipEvent_t freeEv[RT_MAX_LANES] = {};      // recorded behind the last kernel of the batch that used the arena last
+    hipStream_t lastUser[RT_MAX_LANES] = {};   // (a later batch on the same stream is ordered behind it anyway)
+};
+RtArenaPool *rt_arena_pool_create(int arenas) {
+    RtArenaPool *p = new RtArenaPool();
+    p->n = std::max(1, std::min(arenas, (int)RT_MAX_LANES));
+    for (int i = 0; i < p->n; ++i) (void)hipEventCreateWithFlags(&p->freeEv[i], hipEventDisableTiming);
+    return p;
+}
+void rt_arena_pool_destroy(RtArenaPool *p) {
+    if (!p) return;
+    for (int i = 0; i < p->n; ++i) { if (p->mem[i]) (void)hipFree(p->mem[i]); if (p->freeEv[i]) (void)hipEventDestroy(p->freeEv[i]); }
+    delete p;
+}
+int rt_arena_pool_count(const RtArenaPool *p) { return p ? p->n : 0; }
+size_t rt_arena_pool_bytes(const RtArenaPool *p) { size_t b = 0; for (int i = 0; p && i < p->n; ++i) b += p->bytes[i]; return b; }
+
 struct RtWave {
     std::string err;
+    RtArenaPool *pool = nullptr;   // null: this lane owns its arena (chunkArena below)
+    int arena = 0;                 // index into pool
     int cus = 256;
     // ray-queue budget per frame lane; 288 GB of HBM make this cheap.  16 GB hold the queues of a whole batch of eight 1080p / 4 spp frames (7.4 M hits x
     // 2.1 KB) in ONE chunk: no hit-count read-back, half the launches (1.76-1.80 -> 1.68-1.72 ms per frame against 8 GB; profiles/r03_experiments.txt)
     size_t budgetBytes = (size_t)16 << 30;
-    TraceTune tune{32, 16, 0, 2, 0, 0, 0};   // chunk 0 = run length chosen in the kernel from the queue size
+    TraceTune tune{32, 16, 0, 2, 0, 0, 0, 2};   // chunk 0 = run length chosen in the kernel from the queue size
     // allocations
     size_t slotsCap = 0;      // per-frame arrays sized for this many pixel slots
     size_t chunkBytes = 0;    // bytes of the per-chunk arena
-    void *frameArena = nullptr, *chunkArena = nullptr;
+    void *frameArena = nullptr, *chunkArena = nullptr, *resultArena = nullptr;
+    size_t resultBytes = 0;   // per-lane traversal results (what k_combine reads)
     uint32_t *counts = nullptr, *heads = nullptr;
     int launchCap = 0, chunkCap = 0;     // trace launches `heads` holds cursors for / chunks `counts` holds bounce counters for
     unsigned long long *acc = nullptr;   // traced-ray tallies accumulated over frames
     unsigned long long *stats = nullptr; // RT_TRACE_STATS=1: 4 stages x 8 diagnostic sums
     uint32_t *hostHits = nullptr;        // pinned: the hit count of a batch that needs more than one chunk (read back once per batch)
+    bool binGi = false;                  // RT_BIN_GI=1: bounce rays sorted by direction inside each workgroup of k_gen_direct (experiment)
     bool chunksFromSlots = false;        // RT_CHUNKS_FROM_SLOTS=1 (tests): launch the chunk loop for every pixel slot, as rounds 1-2 did
 };
 
-RtWave *rt_wave_create(int cus) {
+RtWave *rt_wave_create(int cus, RtArenaPool *pool, int lane) {
     RtWave *w = new RtWave();
     w->cus = cus > 0 ? cus : 256;
+    w->pool = pool;
+    w->arena = pool ? lane % pool->n : 0;
     if (const char *e = getenv("RT_QUEUE_BUDGET_MB")) w->budgetBytes = (size_t)atoll(e) << 20;
     if (const char *e = getenv("RT_REFILL_MIN")) w->tune.refillMin = std::max(1, std::min(64, atoi(e)));
     if (const char *e = getenv("RT_CHUNK")) { int v = atoi(e); w->tune.chunk = v <= 0 ? 0 : std::max(8, std::min(1 << 20, v)); }   // 0 = from the queue size
     if (const char *e = getenv("RT_DEBUG_SKIP_TRAVERSAL")) w->tune.skipTraversal = atoi(e);
-    if (const char *e = getenv("RT_LEAFB")) w->tune.leafb = atoi(e);
+    if (const char *e = getenv("RT_LEAFB")) w->tune.leafb = w->tune.leafbClosest = atoi(e);
+    if (const char *e = getenv("RT_LEAFB_CLOSEST")) w->tune.leafbClosest = atoi(e);
     if (const char *e = getenv("RT_MIN_SEARCH")) w->tune.minSearch = std::max(0, std::min(64, atoi(e)));
     if (const char *e = getenv("RT_CHUNKS_FROM_SLOTS")) w->chunksFromSlots = atoi(e) != 0;
     if (const char *e = getenv("RT_QUAD_REFILL")) w->tune.quadRefill = atoi(e) != 0;
-    if (const char *e = getenv("RT_COOP")) w->tune.coop = atoi(e);   // quad-cooperative node fetch of the closest-hit launches (measured option)
+    if (const char *e = getenv("RT_COOP")) w->tune.coop = atoi(e);
+    if (const char *e = getenv("RT_BIN_GI")) w->binGi = atoi(e) != 0;   // quad-cooperative node fetch of the closest-hit launches (measured option)
     return w;
 }
 void rt_wave_destroy(RtWave *w) {
     if (!w) return;
     if (w->frameArena) (void)hipFree(w->frameArena);
-    if (w->chunkArena) (void)hipFree(w->chunkArena);
+    if (w->chunkArena && !w->pool) (void)hipFree(w->chunkArena);
+    if (w->resultArena) (void)hipFree(w->resultArena);
     if (w->counts) (void)hipFree(w->counts);
     if (w->heads) (void)hipFree(w->heads);
     if (w->acc) (void)hipFree(w->acc);
@@ -1055,6 +1165,7 @@ void rt_wave_destroy(RtWave *w) {
     delete w;
 }
 const char *rt_wave_error(const RtWave *w) { return w->err.c_str(); }
+size_t rt_wave_frame_bytes(const RtWave *w) { return w ? w->slotsCap * (4 + 4 + 4 + sizeof(HitRec) + 16 + 4 + 8 + 8) + (w->pool ? 0 : w->chunkBytes) + w->resultBytes : 0; }
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -1072,7 +1183,7 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
     const size_t nSlots = (size_t)std::max(host.g.nLocalTiles, 1) * 256 * (size_t)batch;   // pixel slots of all frames of the batch
     const int SPP = std::max(u.spp, 1);
     const int A = (u.enableAO == 1) ? std::max(u.aoSamples, 0) : 0;
-    const int S1 = A + 6 * SPP, S2 = 6 * SPP;
+    const int S1 = A + 4 * SPP + 2, S2 = 6 * SPP;   // WaveBuf::sh1_slot
 
     if (!w->acc) { W_TRY(hipMalloc(&w->acc, 16 * sizeof(unsigned long long))); W_TRY(hipMemsetAsync(w->acc, 0, 16 * sizeof(unsigned long long), st)); }
     // per-frame arena: cand, primT, primTri, hits
@@ -1086,10 +1197,31 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
     const size_t perHit = (size_t)(S1 + SPP + S2) * 36 + (size_t)S1 + (size_t)SPP * 12 + (size_t)S2;
     size_t CH = std::min(nSlots, std::max<size_t>(w->budgetBytes / perHit, 4096));
     CH = align_up(CH, 256);
-    const size_t need = align_up(CH * (size_t)S1 * 32, 256) + align_up(CH * (size_t)S1, 256) + align_up(CH * (size_t)SPP * 32, 256) +
-                        align_up(CH * (size_t)SPP * 8, 256) + align_up(CH * (size_t)S2 * 32, 256) + align_up(CH * (size_t)S2, 256) + align_up(CH * (size_t)SPP * 4, 256) +
+    // ray records + liveness words (read by the traversal launches only: a SHARED arena can be handed on as soon as the last of them is done) ...
+    const size_t need = align_up(CH * (size_t)S1 * 32, 256) + align_up(CH * (size_t)SPP * 32, 256) + align_up(CH * (size_t)S2 * 32, 256) +
                         align_up(CH * (size_t)S1 * 4, 256) + align_up(CH * (size_t)SPP * 4, 256) + align_up(CH * (size_t)S2 * 4, 256) + 4096;
-    if (w->chunkBytes < need) {
+    // ... and the results k_combine reads (1 byte per any-hit ray, 8 per bounce ray, 4 per (hit, sample)): the lane's own
+    const size_t needRes = align_up(CH * (size_t)S1, 256) + align_up(CH * (size_t)SPP * 8, 256) + align_up(CH * (size_t)S2, 256) + align_up(CH * (size_t)SPP * 4, 256) * 2 + 4096;
+    if (w->resultBytes < needRes) {
+        if (w->resultArena) (void)hipFree(w->resultArena);
+        w->resultArena = nullptr;
+        w->resultBytes = 0;
+        W_TRY(hipMalloc(&w->resultArena, needRes));
+        w->resultBytes = needRes;
+    }
+    if (w->pool) {
+        // a shared arena: grown (never shrunk) once its current user is done with it
+        RtArenaPool &P = *w->pool;
+        const int a = w->arena;
+        if (P.bytes[a] < need) {
+            if (P.lastUser[a]) W_TRY(hipEventSynchronize(P.freeEv[a]));
+            if (P.mem[a]) (void)hipFree(P.mem[a]);
+            P.mem[a] = nullptr; P.bytes[a] = 0;
+            W_TRY(hipMalloc(&P.mem[a], need));
+            P.bytes[a] = need;
+        }
+        w->chunkArena = P.mem[a];
+    } else if (w->chunkBytes < need) {
         if (w->chunkArena) (void)hipFree(w->chunkArena);
         w->chunkArena = nullptr;
         w->chunkBytes = 0;
@@ -1111,13 +1243,15 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
         char *q = (char *)w->chunkArena;
         auto take = [&](size_t bytes) { char *r = q; q += align_up(bytes, 256); return r; };
         wb.shO = (float4 *)take(CH * (size_t)S1 * 16); wb.shD = (float4 *)take(CH * (size_t)S1 * 16);
-        wb.occ1 = (uint8_t *)take(CH * (size_t)S1);
         wb.giO = (float4 *)take(CH * (size_t)SPP * 16); wb.giD = (float4 *)take(CH * (size_t)SPP * 16);
-        wb.giT = (float *)take(CH * (size_t)SPP * 4); wb.giTri = (int *)take(CH * (size_t)SPP * 4);
         wb.sh2O = (float4 *)take(CH * (size_t)S2 * 16); wb.sh2D = (float4 *)take(CH * (size_t)S2 * 16);
+        wb.shT = (float *)take(CH * (size_t)S1 * 4); wb.giL = (float *)take(CH * (size_t)SPP * 4); wb.sh2T = (float *)take(CH * (size_t)S2 * 4);
+        q = (char *)w->resultArena;
+        wb.occ1 = (uint8_t *)take(CH * (size_t)S1);
+        wb.giT = (float *)take(CH * (size_t)SPP * 4); wb.giTri = (int *)take(CH * (size_t)SPP * 4);
         wb.occ2 = (uint8_t *)take(CH * (size_t)S2);
         wb.giPos = (int *)take(CH * (size_t)SPP * 4);
-        wb.shT = (float *)take(CH * (size_t)S1 * 4); wb.giL = (float *)take(CH * (size_t)SPP * 4); wb.sh2T = (float *)take(CH * (size_t)S2 * 4);
+        wb.giPerm = w->binGi ? (int *)take(CH * (size_t)SPP * 4) : nullptr;
     }
     wb.CH = (uint32_t)CH; wb.A = A; wb.SPP = SPP;
     int nChunks = (int)((nSlots + CH - 1) / CH);   // upper bound (every pixel slot a hit); cut down to the hit count below
@@ -1187,6 +1321,8 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
         nChunks = (int)((hits + CH - 1) / CH);
         if (nChunks > 0) { CH = align_up((hits + (size_t)nChunks - 1) / (size_t)nChunks, 256); wb.CH = (uint32_t)CH; }
     }
+    // shared arena: everything from here to the last combine reads or writes it
+    if (w->pool && nChunks > 0 && w->pool->lastUser[w->arena] && w->pool->lastUser[w->arena] != st) W_TRY(hipStreamWaitEvent(st, w->pool->freeEv[w->arena], 0));
     for (int c = 0; c < nChunks; ++c) {
         const uint32_t c0 = (uint32_t)((size_t)c * CH);
         const unsigned gridHS = (unsigned)((CH * (size_t)SPP + 255) / 256), gridH = (unsigned)((CH + 255) / 256);
@@ -1223,6 +1359,8 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
             launch_trace<QueueSrc, true>(st, w->cus, gridPct, treeDepth, dFrame, host.sc, q1, &wb.heads[(size_t)(1 + c * 3 + 0) * kHeadWords], w->acc + 3, w->acc + 9, tune, S ? S + 16 : nullptr);
             rt_stage_end(ctx, ST_TRACE_SHADOW, 1, st);
         }
+        // the last traversal launch of the batch is queued: the shared ray arena may go to the next batch (k_combine reads the lane's own result arrays)
+        if (w->pool && c == nChunks - 1) { W_TRY(hipEventRecord(w->pool->freeEv[w->arena], st)); w->pool->lastUser[w->arena] = st; }
         rt_stage_begin(ctx, ST_COMBINE, st);
         hipLaunchKernelGGL(k_combine, dim3(gridH), dim3(256), 0, st, dFrame, tg, wb, c0);
         rt_stage_end(ctx, ST_COMBINE, 1, st);
@@ -1243,8 +1381,15 @@ void rt_wave_trace_closest_indexed(hipStream_t st, int cus, int treeDepth, const
                                    const uint32_t *count, const float4 *o, const float4 *d, float *outT, int *outTri, uint32_t *heads) {
     IndexedSrc q;
     q.idx = idx; q.count = count; q.o = o; q.d = d; q.outT = outT; q.outTri = outTri; q.n = 0;
-    TraceTune tune{32, 16, 0, 2, 0, 0, 0};
+    TraceTune tune{32, 16, 0, 2, 0, 0, 0, 2};
     launch_trace<IndexedSrc, false>(st, cus, 100, treeDepth, dFrame, hostScene, q, heads, nullptr, nullptr, tune, nullptr);
+}
+void rt_wave_trace_closest_compact(hipStream_t st, int cus, int treeDepth, const DevFrame *dFrame, const DevScene &hostScene, const float4 *o, const float4 *d,
+                                   const uint32_t *dst, const uint32_t *count, const uint32_t *flags, uint32_t cap, float *outT, int *outTri, uint32_t *heads) {
+    CompactSrc q;
+    q.o = o; q.d = d; q.dst = dst; q.count = count; q.flags = flags; q.cap = cap; q.outT = outT; q.outTri = outTri; q.n = 0;
+    TraceTune tune{32, 16, 0, 2, 0, 0, 0, 2};
+    launch_trace<CompactSrc, false>(st, cus, 100, treeDepth, dFrame, hostScene, q, heads, nullptr, nullptr, tune, nullptr);
 }
 size_t rt_wave_head_words() { return kHeadWords; }
 

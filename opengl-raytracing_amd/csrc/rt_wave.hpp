@@ -6,8 +6,19 @@
 
 struct RtContext;
 struct RtWave;
+struct RtHybrid;
 
-RtWave *rt_wave_create(int computeUnits);
+// Ray-queue arenas of a context, shared by its frame lanes (round 4): lane l uses arena l % n and waits for the arena's previous user (another
+// lane's batch, from its first shading launch to its last) through an event.  n == number of lanes: every lane its own arena, as in rounds 1-3.
+struct RtArenaPool;
+RtArenaPool *rt_arena_pool_create(int arenas);
+void rt_arena_pool_destroy(RtArenaPool *p);
+size_t rt_arena_pool_bytes(const RtArenaPool *p);
+int rt_arena_pool_count(const RtArenaPool *p);
+size_t rt_wave_frame_bytes(const RtWave *w);   // per-lane frame arrays (candidates, hits, pre-resolve stash)
+size_t rt_hybrid_arena_bytes(const RtHybrid *h);
+
+RtWave *rt_wave_create(int computeUnits, RtArenaPool *pool = nullptr, int lane = 0);
 void rt_wave_destroy(RtWave *w);
 const char *rt_wave_error(const RtWave *w);
 // Renders one frame of a BVH scene into `tg` on `stream`.  `host` is the host copy of *dFrame.  Only the final temporal
@@ -26,6 +37,10 @@ int rt_wave_traced(RtWave *w, hipStream_t stream, unsigned long long *out16, boo
 // pipeline; results to outT / outTri at the same address.  heads: rt_wave_head_words() zeroed uint32 cursor words.
 void rt_wave_trace_closest_indexed(hipStream_t st, int cus, int treeDepth, const rtd::DevFrame *dFrame, const rtd::DevScene &hostScene, const uint32_t *idx,
                                    const uint32_t *count, const float4 *o, const float4 *d, float *outT, int *outTri, uint32_t *heads);
+// The same over a dense array of records o[r] / d[r], r < min(*count, cap); the answer of record r goes to outT / outTri at dst[r].
+// Nothing is traced when *flags has bit 2 or 4 set (rt_hybrid.hip: a pass that outgrew its arrays left the queue incomplete).
+void rt_wave_trace_closest_compact(hipStream_t st, int cus, int treeDepth, const rtd::DevFrame *dFrame, const rtd::DevScene &hostScene, const float4 *o, const float4 *d,
+                                   const uint32_t *dst, const uint32_t *count, const uint32_t *flags, uint32_t cap, float *outT, int *outTri, uint32_t *heads);
 size_t rt_wave_head_words();
 
 // rt_hybrid.hip -- EXTENSION: the hybrid scene (analytic objects + mesh, N diffuse bounces) in stages: shading passes that replay answered mesh

@@ -44,11 +44,14 @@ struct Scene {
     int envSize = 0, envCh = 0;
     const uint16_t *prev = nullptr; // W*H*4 half, previous COLOR0
     int W = 0, H = 0;
+    int envFilter = 0;              // cube-map filter model: 0 exact fp32 weights, 1 texel coordinates rounded to 1/256 texel
     int giBounces = 1;              // EXTENSION (not in the reference): diffuse bounces of the analytic / hybrid GI path, see giPath
 };
 // EXTENSION, not in the reference (SURVEY.md 8d config 3 "run B", labelled mode=hybrid): uUseBVH == 2 renders the analytic branch of
 // rt.frag with the BVH mesh added to the analytic scene as one more object.  Everything else is the reference's analytic code.
 static const int kSceneHybrid = 2;
+// cube-map filter model (Scene::envFilter) for the orc_render / orc_texture_cube calls that follow.  0 = exact fp32 weights (default).
+static std::atomic<int> g_envFilter{0};
 static const int MAT_MESH = 5;      // no material of rt_materials.glsl:20-24 -> getMaterial's default branch (:123-124): 0.8 grey, spec 0.2, gloss 16, diffuse
 
 // ---------------------------------------------------------------- rt_common.glsl
@@ -208,6 +211,10 @@ static vec3 textureCube(const Scene &S, Counters &C, vec3 d) {
     float t = 0.5f * (tc / ma + 1.0f);
     const int N = S.envSize, ch = S.envCh;
     float fu = s * (float)N - 0.5f, fv = t * (float)N - 0.5f;
+    if (S.envFilter == 1) {   // SURVEY.md 8c's second mode: GPU samplers filter RGB8 with ~8 bits of sub-texel precision -- coordinates rounded
+        fu = std::floor(fu * 256.0f + 0.5f) * 0.00390625f;   // to nearest on a 1/256-texel grid; everything after is unchanged
+        fv = std::floor(fv * 256.0f + 0.5f) * 0.00390625f;
+    }
     float flu = std::floor(fu), flv = std::floor(fv);
     float a = fu - flu, b = fv - flv;
     int i0 = (int)flu, j0 = (int)flv;
@@ -811,7 +818,7 @@ void orc_sample_hemisphere(float pi, const float *N, float ux, float uy, float *
     Scene S; S.u.pi = pi; vec3 r = sampleHemisphereCosine(S, ld3(N), vec2{ux, uy}); out[0] = r.x; out[1] = r.y; out[2] = r.z;
 }
 void orc_texture_cube(const uint8_t *faces, int faceSize, int ch, const float *dir, float *out) {
-    Scene S; Counters C; S.env = faces; S.envSize = faceSize; S.envCh = ch;
+    Scene S; Counters C; S.env = faces; S.envSize = faceSize; S.envCh = ch; S.envFilter = g_envFilter;
     vec3 r = textureCube(S, C, ld3(dir)); out[0] = r.x; out[1] = r.y; out[2] = r.z;
 }
 // Single closest-hit / any-hit queries against a reference-layout BVH (unit tests).
@@ -870,6 +877,7 @@ int orc_trace_bvh_shadow(const OrcUniforms *u, const float *nodes, const float *
 // EXTENSION knob (see Scene::giBounces): bounces of the analytic / hybrid GI path for the orc_render calls that follow.  1 = the reference.
 static std::atomic<int> g_giBounces{1};
 void orc_set_gi_bounces(int n) { g_giBounces = n; }
+void orc_set_env_filter(int m) { g_envFilter = m; }
 
 int orc_render(const OrcUniforms *u, const float *nodes12, const float *tris12, const uint8_t *envFaces, int envFaceSize,
                int envChannels, const uint16_t *prevAccum, uint16_t *outColor, uint16_t *outMotion, uint16_t *outGPos,
@@ -880,6 +888,7 @@ int orc_render(const OrcUniforms *u, const float *nodes12, const float *tris12, 
     S.env = envFaces; S.envSize = envFaceSize; S.envCh = envChannels;
     S.prev = prevAccum;
     S.giBounces = g_giBounces;
+    S.envFilter = g_envFilter;
     S.W = (int)u->resolution[0]; S.H = (int)u->resolution[1];
     if (S.W <= 0 || S.H <= 0) return -1;
     if (u->useEnvMap == 1 && (!envFaces || envFaceSize <= 0 || envChannels < 3)) return -2;

@@ -53,6 +53,7 @@ def load(path):
     L.orc_render.argtypes = [C.POINTER(rt.RtUniforms), _FP, _FP, _U8P, C.c_int, C.c_int, _U16P, _U16P, _U16P, _U16P, _U16P,
                              C.c_int, C.c_int, C.c_int, C.c_int, _U8P, C.c_int, C.POINTER(OrcCounters)]
     L.orc_set_gi_bounces.argtypes = [C.c_int]
+    L.orc_set_env_filter.argtypes = [C.c_int]
     return L
 
 
@@ -83,6 +84,7 @@ def lib():
     L.orc_render.argtypes = [C.POINTER(rt.RtUniforms), _FP, _FP, _U8P, C.c_int, C.c_int, _U16P, _U16P, _U16P, _U16P, _U16P,
                              C.c_int, C.c_int, C.c_int, C.c_int, _U8P, C.c_int, C.POINTER(OrcCounters)]
     L.orc_set_gi_bounces.argtypes = [C.c_int]
+    L.orc_set_env_filter.argtypes = [C.c_int]
     L.orc_default_render_params.argtypes = [C.POINTER(rt.RtRenderParams)]
     L.orc_default_camera.argtypes = [C.POINTER(rt.RtCamera)]
     L.orc_default_bvh_transform.argtypes = [_FP]
@@ -195,10 +197,12 @@ def cubemap_from_cross(img):
     return faces
 
 
-def render(u, nodes12=None, tris12=None, env_faces=None, prev=None, region=None, mask=None, nthreads=8, L=None, gi_bounces=1):
+def render(u, nodes12=None, tris12=None, env_faces=None, prev=None, region=None, mask=None, nthreads=8, L=None, gi_bounces=1, env_filter=0):
     """One frame by the oracle -> ([color, motion, gpos, gnrm] uint16 arrays HxWxC, OrcCounters).  L: a library from load().
-    gi_bounces: EXTENSION knob of the analytic / hybrid GI path (1 = the reference)."""
+    gi_bounces: EXTENSION knob of the analytic / hybrid GI path (1 = the reference).  env_filter: cube-map filter model (0 = exact
+    fp32 weights, 1 = texel coordinates rounded to 1/256 texel)."""
     (L or lib()).orc_set_gi_bounces(int(gi_bounces))
+    (L or lib()).orc_set_env_filter(int(env_filter))
     W, H = int(u.resolution[0]), int(u.resolution[1])
     outs = [np.zeros((H, W, c), np.uint16) for c in (4, 2, 4, 4)]
     n = None if nodes12 is None else _f32(nodes12)

@@ -125,6 +125,72 @@ def test_analytic_scene_frames(ren, orc, env):
         prev = want[0]
 
 
+@pytest.mark.parametrize("use_bvh", [False, True])
+def test_cubemap_quantised_filter_mode(orc, use_bvh):
+    """RtExtension.envFilter = 1 (SURVEY.md 8c's second cube-map filter model: texel coordinates rounded to 1/256 texel): HIP == oracle bit
+    for bit in that mode too, on the analytic scene (megakernel) and on a BVH scene (wavefront pipeline), and the mode is not a no-op --
+    the frame differs from the default model's, by less than an 8-bit step of the environment (x envIntensity) per sky lookup."""
+    W, H = 128, 96
+    faces = scenes.env_faces("Sky_16")
+    nodes, tris = scenes.bunny_bvh(3)
+    p = rt.default_render_params()
+    p.sppPerFrame = 2
+    cam = scenes.camera("closeup" if use_bvh else "default", aspect=W / H)
+    frames = {}
+    for mode in (0, 1):
+        with rt.Renderer() as r:
+            r.upload_bvh(nodes, tris)
+            r.upload_env(faces)
+            r.resize(W, H)
+            r.set_extension(env_filter=mode)
+            prev = None
+            for f in range(2):
+                u = rt.frame_uniforms(p, cam, W, H, f, use_bvh, nodes.shape[0], tris.shape[0])
+                r.render_frame(u)
+                got = r.read_all()
+                want, _ = orc.render(u, nodes, tris, faces, prev, env_filter=mode)
+                _assert_targets_equal(got, want, orc, f"env_filter={mode} bvh={use_bvh} frame={f}")
+                prev = want[0]
+            frames[mode] = got[0]
+    d = orc.compare(frames[0], frames[1])
+    assert d["bit_diff"] > 0 and d["max_abs"] < 0.05, d
+    with rt.Renderer() as r, pytest.raises(rt.RtError):
+        r.set_extension(env_filter=2)
+
+
+@pytest.mark.parametrize("mesh", ["one_leaf", "tiny", "deep"])
+def test_anyhit_sah_tree_option(orc, monkeypatch, mesh):
+    """RT_ANYHIT_TREE=sah (the option lives in rt_upload_bvh, so it gets a test): the any-hit launches of the wavefront pipeline walk a
+    binned-SAH 4-wide tree over the reference's leaves instead of the collapse of the median-split tree.  Any-hit answers depend only on which
+    reference leaves pass their own box test, so the frames must stay bit-identical to the oracle -- on a single-leaf mesh (the option must leave
+    it alone), a 20-triangle mesh (one level) and a 5 120-triangle mesh (depth-12 tree, deep SAH tree)."""
+    monkeypatch.setenv("RT_ANYHIT_TREE", "sah")        # read by rt_upload_bvh
+    W, H = 96, 64
+    if mesh == "one_leaf":
+        tris9 = np.array([[-1, 0, -1, 1, 0, -1, 0, 1.5, -1.2], [-1, 0, 1, 1, 0, 1, 0, 1.5, 0.5]], np.float32) + np.float32(0.25)
+        nodes, tris = rt.build_bvh(tris9)
+        assert nodes.shape[0] == 1
+    else:
+        nodes, tris = scenes.bunny_bvh(0 if mesh == "tiny" else 4)
+    faces = scenes.tiny_env(8)
+    p = rt.default_render_params()
+    p.sppPerFrame = 2
+    cam = scenes.camera("closeup", aspect=W / H)
+    with rt.Renderer(pipeline=rt.RT_PIPELINE_WAVEFRONT) as r:
+        r.upload_bvh(nodes, tris)
+        r.upload_env(faces)
+        r.resize(W, H)
+        prev = None
+        for f in range(2):
+            u = rt.frame_uniforms(p, cam, W, H, f, True, nodes.shape[0], tris.shape[0])
+            r.render_frame(u)
+            want, _ = orc.render(u, nodes, tris, faces, prev)
+            _assert_targets_equal(r.read_all(), want, orc, f"RT_ANYHIT_TREE=sah {mesh} frame={f}")
+            prev = want[0]
+        tr = r.traced_rays()
+        assert mesh == "one_leaf" or tr.shadow > 0
+
+
 @pytest.fixture(scope="module")
 def ren_wave():
     r = rt.Renderer(pipeline=rt.RT_PIPELINE_WAVEFRONT)

@@ -141,15 +141,19 @@ print("STAGED-OK")
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("budget_mb,w,h,spp,bounces", [(8192, 640, 360, 4, 4), (16, 320, 200, 3, 2)])
-def test_staged_hybrid_equals_the_megakernel(budget_mb, w, h, spp, bounces):
+@pytest.mark.parametrize("budget_mb,w,h,spp,bounces,extra", [(8192, 640, 360, 4, 4, {}), (1, 320, 200, 3, 2, {}),
+                                                             (8192, 320, 200, 4, 4, {"RT_HYBRID_RATIO_Q": "0.02", "RT_HYBRID_RATIO_L": "0.02"}),
+                                                             (2, 320, 200, 2, 2, {"RT_HYBRID_RATIO_Q": "0.05", "RT_HYBRID_RATIO_L": "0.05"})])
+def test_staged_hybrid_equals_the_megakernel(budget_mb, w, h, spp, bounces, extra):
     """The staged hybrid pipeline against the megakernel on a frame that shows everything at once -- mesh, floor, diffuse / glass / mirror
-    spheres, light marker, N bounces, three frames of accumulation -- bit for bit; the second case cuts the frame into many chunks of
-    pixel slots (16 MB of queue + log)."""
+    spheres, light marker, N bounces, three frames of accumulation -- bit for bit; the second case cuts the frame into some twenty chunks of
+    pixel slots (1 MB of per-thread state + queue + log); the third and fourth start with capacity estimates fifty / twenty times too small for the
+    dense queue and the log arena, so that the first passes outgrow them, only count, and the chunk is rendered again with enlarged arrays
+    (round 4: memory follows the recorded queries; the estimates are the one thing that can be wrong) -- also in combination with chunking."""
     import os
     import subprocess
     import sys
-    env = dict(os.environ, RT_QUEUE_BUDGET_MB=str(budget_mb))
+    env = dict(os.environ, RT_QUEUE_BUDGET_MB=str(budget_mb), **extra)
     r = subprocess.run([sys.executable, "-c", _STAGED_CODE, str(w), str(h), str(spp), str(bounces)], cwd=str(scenes.ROOT), env=env, capture_output=True, text=True, timeout=900)
     assert "STAGED-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 

@@ -171,6 +171,37 @@ def test_cubemap_face_selection_and_filtering(orc):
     np.testing.assert_allclose(tex((s, -t, 1))[1], 75 / 255, atol=1e-6)
 
 
+def test_cubemap_quantised_filter_mode(orc):
+    """SURVEY.md 8c's second filter model (RtExtension.envFilter = 1): texel coordinates rounded to 1/256 texel before the bilinear weights.
+    Same texels / faces / clamping; on face interiors the two modes differ by at most 1/255 per channel (coordinates move by <= 1/512 texel,
+    a texel step is <= 255/255); at texel centres and at multiples of 1/256 they agree exactly."""
+    rng = np.random.default_rng(5)
+    n = 8
+    faces = rng.integers(0, 256, (6, n, n, 3), dtype=np.uint8)
+    L = orc.lib()
+    out = np.zeros(3, np.float32)
+
+    def tex(d, mode):
+        d = np.asarray(d, np.float32)
+        L.orc_set_env_filter(mode)
+        L.orc_texture_cube(faces.ctypes.data_as(C.POINTER(C.c_uint8)), n, 3, d.ctypes.data_as(C.POINTER(C.c_float)), out.ctypes.data_as(C.POINTER(C.c_float)))
+        L.orc_set_env_filter(0)
+        return out.copy()
+    worst, differ = 0.0, 0
+    for d in rng.normal(size=(4000, 3)):
+        a, b = tex(d, 0), tex(d, 1)
+        worst = max(worst, float(np.abs(a - b).max()))
+        differ += int(not np.array_equal(a, b))
+    assert worst <= 1.0 / 255.0 + 1e-6 and differ > 3000          # a different model, within one 8-bit step
+    # a coordinate on the 1/256 grid: +Z face, s*N - 0.5 = 2 + 64/256 exactly, t at a texel centre -> identical weights in both modes
+    s_ = (2.25 + 0.5) / n * 2 - 1
+    t_ = (3 + 0.5) / n * 2 - 1
+    assert np.array_equal(tex((s_, -t_, 1), 0), tex((s_, -t_, 1), 1))
+    # mode 1 snaps: coordinates 1/1024 texel apart give the same result
+    eps_ = (1.0 / 1024) / n * 2
+    assert np.array_equal(tex((s_ + eps_, -t_, 1), 1), tex((s_, -t_, 1), 1)) and not np.array_equal(tex((s_ + eps_, -t_, 1), 0), tex((s_, -t_, 1), 0))
+
+
 def test_cubemap_cross_slicing(orc):
     n = 3
     img = np.zeros((3 * n, 4 * n, 3), np.uint8)
