@@ -469,10 +469,11 @@ def main():
         # at least once: the ray records it reads (32-byte origin/direction + 4-byte tMax; 4 bytes of pixel slot for a primary ray), the
         # results it writes (1 byte per any-hit ray, 8 per closest-hit ray) and the BVH arrays it walks, once (every re-read of
         # a node is served by L1 / L2 / Infinity Cache or is waste).
-        rays_k = {"trace_primary": tr.primary, "trace_shadow": tr.shadow + tr.bounceShadow, "trace_gi": tr.bounce}
-        rec_k = {"trace_primary": 4 + 8, "trace_shadow": 36 + 1, "trace_gi": 36 + 8}
+        # trace_ao (round 4): the AO rays of a hit are one packet -- one 16-byte origin for its four rays, 16-byte direction + 4-byte tMax in and 1 byte out per ray
+        rays_k = {"trace_primary": tr.primary, "trace_shadow": tr.shadow + tr.bounceShadow, "trace_gi": tr.bounce, "trace_ao": tr.ao}
+        rec_k = {"trace_primary": 4 + 8, "trace_shadow": 36 + 1, "trace_gi": 36 + 8, "trace_ao": 4 + 16 + 4 + 1}
         bvh_k = {"trace_primary": info.bytesNodes2 + info.bytesPairs, "trace_shadow": info.bytesNodes4 + info.bytesPairs,
-                 "trace_gi": info.bytesNodes2 + info.bytesPairs}
+                 "trace_gi": info.bytesNodes2 + info.bytesPairs, "trace_ao": info.bytesNodes4 + info.bytesPairs}
         if name in rays_k:
             rays_per_launch = rays_k[name] / launches
             bytes_per_launch = rays_per_launch * rec_k[name] + bvh_k[name]
@@ -499,8 +500,8 @@ def main():
         # passes over THIS command in its batched mode, gfx950 2x fetch correction).  PMC cannot be collected inside this run: the figure is
         # accepted only when the kernel sources it was measured on are the ones running now, else it is dropped.
         traffic, traffic_src = None, None
-        kmap = {"trace_shadow": "DualQueueSrc, true", "trace_gi": "QueueSrc, false", "trace_primary": "PrimarySrc"}
-        tj = ROOT / "profiles" / ("r03_traffic_%s.json" % ("1m" if args.scene == "1m" else "bunny"))
+        kmap = {"trace_shadow": "DualQueueSrc, true", "trace_gi": "QueueSrc, false", "trace_primary": "PrimarySrc", "trace_ao": "k_trace_packets"}
+        tj = ROOT / "profiles" / ("r04_traffic_%s.json" % ("1m" if args.scene == "1m" else "bunny"))
         if world == 1 and tj.exists() and name in kmap and (W, H, SPP, B) == (1920, 1080, 4, 8) and not args.obj:
             tjd = json.load(open(tj))
             if tjd.get("kernel_source_sha256") == kernel_source_sha():
@@ -518,7 +519,7 @@ def main():
         # lanes of a wave that read the same record (one access).  frac = merged accesses / launch duration / (256 CUs x 2.4 GHz) <= 1.
         l1 = None
         gl = {"trace_primary": tr.gatherLoadsPrimary, "trace_shadow": tr.gatherLoadsShadow, "trace_gi": tr.gatherLoadsBounce}
-        if name in gl and merged is not None:
+        if name in gl and merged is not None:   # (the packet launch has no instrumented build: every record it fetches is fetched once per packet by construction)
             mg = {"trace_primary": (merged.mergedLoadsPrimary, merged.gatherLoadsPrimary), "trace_shadow": (merged.mergedLoadsShadow, merged.gatherLoadsShadow),
                   "trace_gi": (merged.mergedLoadsBounce, merged.gatherLoadsBounce)}[name]
             if mg[1] > 0 and mg[0] > 0:

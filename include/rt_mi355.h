@@ -309,12 +309,14 @@ typedef struct RtTracedRays {
     uint64_t candidatePixels, hitPixels, primary, shadow, bounce, bounceShadow, frames;
     uint64_t gatherLoadsPrimary, gatherLoadsShadow, gatherLoadsBounce;
     uint64_t mergedLoadsPrimary, mergedLoadsShadow, mergedLoadsBounce;
+    uint64_t ao, gatherLoadsAO;   /* AO rays traced as packets (one walk of the tree for the rays of a hit, round 4; not contained in `shadow`) and
+                                   * the gather loads of that launch */
 } RtTracedRays;
 int rt_get_traced_rays(RtContext *ctx, RtTracedRays *out, int reset);
 
 /* Device timing of the dominant kernel(s): HIP events recorded on the context's stream around each
  * stage of every frame since the last reset.  stage names: rt_stage_name(i). */
-#define RT_MAX_STAGES 13
+#define RT_MAX_STAGES 14
 typedef struct RtStageTimes { int32_t nStages; int32_t frames; double ms[RT_MAX_STAGES]; uint64_t launches[RT_MAX_STAGES]; } RtStageTimes;
 int rt_enable_stage_timing(RtContext *ctx, int enable);
 int rt_get_stage_times(RtContext *ctx, RtStageTimes *out);   /* synchronises */

@@ -25,7 +25,7 @@ RT_TARGET_COLOR, RT_TARGET_MOTION, RT_TARGET_GPOS, RT_TARGET_GNRM = 0, 1, 2, 3
 RT_FORMAT_F16, RT_FORMAT_F32 = 0, 1
 RT_PIPELINE_AUTO, RT_PIPELINE_MEGAKERNEL, RT_PIPELINE_WAVEFRONT = 0, 1, 2
 TARGET_CHANNELS = {0: 4, 1: 2, 2: 4, 3: 4}
-RT_MAX_STAGES = 13
+RT_MAX_STAGES = 14
 RT_COMM_ID_BYTES = 128
 
 f32, i32 = C.c_float, C.c_int32
@@ -130,11 +130,11 @@ class RtCommInfo(_Struct):
 class RtTracedRays(_Struct):
     _fields_ = [(n, C.c_uint64) for n in ("candidatePixels", "hitPixels", "primary", "shadow", "bounce", "bounceShadow", "frames",
                                              "gatherLoadsPrimary", "gatherLoadsShadow", "gatherLoadsBounce",
-                                             "mergedLoadsPrimary", "mergedLoadsShadow", "mergedLoadsBounce")]
+                                             "mergedLoadsPrimary", "mergedLoadsShadow", "mergedLoadsBounce", "ao", "gatherLoadsAO")]
 
     @property
     def rays(self):
-        return self.primary + self.shadow + self.bounce + self.bounceShadow
+        return self.primary + self.shadow + self.bounce + self.bounceShadow + self.ao
 
 
 class RtSceneInfo(_Struct):

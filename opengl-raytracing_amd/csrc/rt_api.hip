@@ -117,7 +117,7 @@ static hipError_t sync_all(RtContext *c) {
 
 static const char *kStageNames[RT_MAX_STAGES] = {"mega",     "primary", "trace_primary",   "post_primary", "gen_direct", "trace_shadow",
                                                  "trace_gi", "gen_gi",  "resolve",         "combine",      "assemble",   "present",
-                                                 "gather"};   // gather: the whole of rt_gather_frame on its stream (copy / send / recv / un-tiling; "assemble" lies inside it)
+                                                 "gather", "trace_ao"};   // gather: the whole of rt_gather_frame on its stream (copy / send / recv / un-tiling; "assemble" lies inside it)
 
 // ------------------------------------------------------------------------------------------------
 namespace {
@@ -350,9 +350,17 @@ int rt_create(const RtDeviceConfig *cfg, RtContext **out) {
     // frames wait for their predecessor from the first kernel on.
     if (c->nLanes == 1) { c->nLanes = 2; c->serialFrames = true; }
     bool ok = hipMalloc(&c->dCounters, 16 * sizeof(unsigned long long)) == hipSuccess;
+    // EXPERIMENT RT_CU_SPLIT=k (rt_wave.hip): the lanes' own streams -- the traversal launches -- keep 8 - k eighths of the CUs
+    uint32_t cuMask[8];
+    bool masked = false;
+    if (const char *e = getenv("RT_CU_SPLIT")) {
+        const int k = std::max(1, std::min(7, atoi(e)));
+        for (int i = 0; i < 8; ++i) { uint32_t m = 0; for (int b = 0; b < 32; ++b) if (((i * 32 + b) & 7) >= k) m |= 1u << b; cuMask[i] = m; }
+        masked = true;
+    }
     for (int i = 0; ok && i < c->nLanes; ++i)
-        ok = hipStreamCreateWithFlags(&c->lanes[i], hipStreamNonBlocking) == hipSuccess && hipMalloc(&c->dFrame[i], sizeof(DevFrame)) == hipSuccess &&
-             hipEventCreateWithFlags(&c->evDone[i], hipEventDisableTiming) == hipSuccess;
+        ok = (masked ? hipExtStreamCreateWithCUMask(&c->lanes[i], 8, cuMask) : hipStreamCreateWithFlags(&c->lanes[i], hipStreamNonBlocking)) == hipSuccess &&
+             hipMalloc(&c->dFrame[i], sizeof(DevFrame)) == hipSuccess && hipEventCreateWithFlags(&c->evDone[i], hipEventDisableTiming) == hipSuccess;
     if (!ok) {
         rt_destroy(c);
         return fail(nullptr, RT_ERR_HIP, "rt_create: stream/alloc failed");
@@ -1136,6 +1144,7 @@ int rt_get_traced_rays(RtContext *c, RtTracedRays *out, int reset) {
     out->bounceShadow = v[5]; out->frames = v[6];
     out->gatherLoadsPrimary = v[8]; out->gatherLoadsShadow = v[9]; out->gatherLoadsBounce = v[10];
     out->mergedLoadsPrimary = v[11]; out->mergedLoadsShadow = v[12]; out->mergedLoadsBounce = v[13];
+    out->ao = v[7]; out->gatherLoadsAO = v[14];
     return RT_OK;
 }
 

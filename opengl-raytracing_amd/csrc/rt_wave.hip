@@ -43,7 +43,7 @@
 using namespace rtd;
 
 // stage ids (rt_stage_name in rt_api.hip)
-enum { ST_PRIMARY = 1, ST_TRACE_PRIMARY, ST_POST_PRIMARY, ST_GEN_DIRECT, ST_TRACE_SHADOW, ST_TRACE_GI, ST_GEN_GI, ST_RESOLVE, ST_COMBINE };
+enum { ST_PRIMARY = 1, ST_TRACE_PRIMARY, ST_POST_PRIMARY, ST_GEN_DIRECT, ST_TRACE_SHADOW, ST_TRACE_GI, ST_GEN_GI, ST_RESOLVE, ST_COMBINE, ST_TRACE_AO = 13 };
 
 struct HitRec { uint32_t slot; float t; int tri; };
 
@@ -806,6 +806,242 @@ __global__ __launch_bounds__(256, (!STATS && !ANY) ? 5 : 1) void k_trace(const D
     }
 }
 
+// ---- packet traversal (round 4) ----------------------------------------------------------------------
+// The AO rays of one hit leave from ONE point (computeAO: org = hp + N * aoBias, rt_lighting.glsl:721-757) and are short (aoRadius 0.8): the
+// four of them visit nearly the same part of the tree -- traced one by one they fetch 39.8 four-wide node records and 8.8 leaves per hit on the
+// bench mesh, as a packet 14.0 and 3.7 (tools/r04_packet_proto.py).  They are 83 % of the any-hit rays of a frame, and the any-hit launch runs at
+// the vector L1's access rate.  So one LANE walks the tree once for the up to four rays of a hit: every node record and every
+// triangle record is fetched once and tested against the rays that entered its parent (a 4-bit mask travels with every stack entry), a ray leaves
+// the packet when it is occluded.  Every (ray, box) and (ray, triangle) test is the arithmetic of the single-ray kernel on the same operands, and a
+// ray's answer is the OR over the reference's leaves whose own box the ray passes ("any-hit rays walk 4-wide nodes") -- which is
+// what this computes, in another order -- so the answers are the same bits.
+struct PacketSrc {       // packet p -> hit j = p % nLive, ray group g = p / nLive: rays i = 4 g .. 4 g + 3 (< A) at [i * stride + j]
+    const float4 *o, *d;
+    const float *tm;
+    uint8_t *occ;
+    const uint32_t *liveCount;
+    uint32_t c0, cap, stride;
+    int A;
+    uint32_t nLive;
+    RT_DEV void prepare() { uint32_t h = *liveCount; nLive = min(h, c0 + cap) - min(h, c0); }
+    RT_DEV uint32_t size() const { return nLive * (uint32_t)((A + 3) / 4); }
+};
+// stack / register entry: [31:28] rays of the packet that passed the node's box, [27] leaf, [26:0] inner node index or leaf code (first << 3 | count - 1); 0 = none
+RT_DEV uint32_t pk_entry(uint32_t mask, int ref) { return (mask << 28) | (ref < 0 ? (0x08000000u | (uint32_t)(-ref - 1)) : (uint32_t)ref); }
+RT_DEV bool pk_is_leaf(uint32_t e) { return (e & 0x08000000u) != 0u; }
+
+__global__ __launch_bounds__(256, 4) void k_trace_packets(const DevFrame *__restrict__ fr, const float4 *__restrict__ w4, const float4 *__restrict__ pairs, PacketSrc src,
+                                                          uint32_t *head, unsigned long long *tally, unsigned long long *gatherLoads, TraceTune tune, int stackEntries) {
+    uint32_t *stk = reinterpret_cast<uint32_t *>(rt_dyn_lds) + (threadIdx.x >> 6) * stackEntries * 64 + (threadIdx.x & 63);
+    const DevScene sc = fr->sc;
+    const float eps = fr->u.eps;
+    src.prepare();
+    const uint32_t n = src.size();
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t runLen = tune.chunk > 0 ? (uint32_t)max(tune.chunk, 8) : min(256u, max(64u, ((n / (3u * 4u * gridDim.x) + 63u) / 64u) * 64u));
+    // per-lane packet state
+    V3 ro = mk3(0.0f), rd[4], rdInv[4];
+    float tMax[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { rd[r] = mk3(0.0f); rdInv[r] = mk3(0.0f); tMax[r] = -1.0f; }
+    uint32_t alive = 0;          // rays of the packet not decided yet
+    uint32_t occl = 0;           // rays found occluded
+    uint32_t cur = 0, leafE = 0; // node in hand / postponed leaf (entries, 0 = none)
+    int sp = 0;
+    uint32_t token = 0;          // address of the packet's first ray
+    uint32_t nRays = 0;          // rays of the packet that exist (i < A)
+    bool active = false;
+    bool exhausted = (n == 0);
+    uint32_t traced = 0, gathers = 0;
+    uint32_t runNext = 0, runEnd = 0;
+    const uint32_t shard = (blockIdx.x * 4u + (threadIdx.x >> 6)) % kShards;
+    bool homeDry = false;
+    const uint32_t nRuns = (n + runLen - 1u) / runLen;
+
+    auto retire = [&]() {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if ((uint32_t)r < nRays && !(tMax[r] < 0.0f)) src.occ[token + (uint32_t)r * src.stride] = (occl >> r) & 1u;
+        active = false;
+    };
+    auto pop_or_finish = [&]() {
+        cur = 0;
+        while (sp > 0) {
+            sp--;
+            uint32_t e = stk[sp * 64];
+            const uint32_t m = (e >> 28) & alive;
+            if (m == 0u) continue;                              // every ray that entered this subtree has been decided since
+            e = (e & 0x0fffffffu) | (m << 28);
+            if (pk_is_leaf(e) && leafE == 0u) { leafE = e; continue; }   // leaves wait; keep looking for an inner node
+            cur = e;                                                      // an inner node, or a second leaf (the lane then waits)
+            break;
+        }
+        if (cur == 0u && leafE == 0u) retire();
+    };
+
+    for (;;) {
+        const unsigned long long idleMask = __ballot(!active);
+        const int nIdle = __popcll(idleMask);
+        if (!exhausted && nIdle >= tune.refillMin) {
+            if (runNext >= runEnd) {
+                auto runsOf = [&](uint32_t sh) { return sh < nRuns ? (nRuns - sh + kShards - 1u) / kShards : 0u; };
+                uint32_t k = 0, from = shard;
+                bool got = false;
+                if (!homeDry) {
+                    if (lane == 0) k = atomicAdd(&head[shard * kShardStride], 1u);
+                    k = __shfl(k, 0, 64);
+                    got = k < runsOf(shard);
+                    homeDry = !got;
+                }
+                while (!got) {
+                    const uint32_t c = __hip_atomic_load(&head[lane * kShardStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    unsigned long long open = __ballot(c < runsOf(lane));
+                    if (open == 0ull) break;
+                    const unsigned long long rot = (open >> shard) | (shard ? (open << (64u - shard)) : 0ull);
+                    from = (shard + (uint32_t)__ffsll((long long)rot) - 1u) % kShards;
+                    if (lane == 0) k = atomicAdd(&head[from * kShardStride], 1u);
+                    k = __shfl(k, 0, 64);
+                    got = k < runsOf(from);
+                }
+                if (!got) { exhausted = true; continue; }
+                const unsigned long long base = ((unsigned long long)k * kShards + from) * runLen;
+                runNext = (uint32_t)base;
+                runEnd = (uint32_t)min((unsigned long long)n, base + runLen);
+            }
+            // every packet of the run exists: the i-th idle lane takes the i-th packet left
+            const uint32_t nTake = min((uint32_t)nIdle, runEnd - runNext);
+            const uint32_t rank = (uint32_t)__popcll(idleMask & ((1ull << lane) - 1ull));
+            if (!active && rank < nTake) {
+                const uint32_t p = runNext + rank;
+                const uint32_t g = p / src.nLive, j = p % src.nLive;
+                token = (4u * g) * src.stride + j;
+                nRays = min(4u, (uint32_t)src.A - 4u * g);
+                ro = f4xyz(src.o[token]);        // one origin for the packet
+                alive = 0; occl = 0; sp = 0; cur = 0; leafE = 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    tMax[r] = -1.0f;
+                    if ((uint32_t)r < nRays) {
+                        const uint32_t a = token + (uint32_t)r * src.stride;
+                        tMax[r] = src.tm[a];
+                        if (!(tMax[r] < 0.0f)) {
+                            rd[r] = f4xyz(src.d[a]);
+                            rdInv[r] = mk3(1.0f / rd[r].x, 1.0f / rd[r].y, 1.0f / rd[r].z);
+                            traced++;
+                            float tmin;
+                            if (sc.hasBVH && !tune.skipTraversal && slab(ro, rdInv[r], ld3(sc.rootMin), ld3(sc.rootMax), tmin) && !(tmin > tMax[r])) alive |= 1u << r;
+                        }
+                    }
+                }
+                active = true;
+                if (alive == 0u) retire();
+                else {
+                    const uint32_t e = pk_entry(alive, sc.rootRef4);
+                    if (pk_is_leaf(e)) leafE = e; else cur = e;   // (single-leaf tree)
+                }
+            }
+            runNext += nTake;
+            continue;
+        }
+        if (__ballot(active) == 0ull) {
+            if (exhausted) break;
+            continue;
+        }
+        // ---- inner nodes
+        for (;;) {
+            const bool searching = active && cur != 0u && !pk_is_leaf(cur);
+            const unsigned long long sm = __ballot(searching);
+            if (sm == 0ull) break;
+            if (__popcll(sm) < tune.minSearch && __ballot(active && leafE != 0u) != 0ull) break;
+            if (searching) {
+                gathers += 7u;
+                const uint32_t pm = cur >> 28;
+                const v4f *ndv = reinterpret_cast<const v4f *>(w4 + (size_t)(cur & 0x07ffffffu) * 8);
+                v4f q0 = ndv[0], q1 = ndv[1], q2 = ndv[2], q3 = ndv[3], q4 = ndv[4], q5 = ndv[5], q6 = ndv[6];
+                pin(q0); pin(q1); pin(q2); pin(q3); pin(q4); pin(q5); pin(q6);
+                uint32_t cm0 = 0, cm1 = 0, cm2 = 0, cm3 = 0;   // per child: the rays that pass its box
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float t0, t1, t2, t3;
+                    const bool h0 = slab(ro, rdInv[r], mk3(q0.x, q1.x, q2.x), mk3(q3.x, q4.x, q5.x), t0) && t0 <= tMax[r];
+                    const bool h1 = slab(ro, rdInv[r], mk3(q0.y, q1.y, q2.y), mk3(q3.y, q4.y, q5.y), t1) && t1 <= tMax[r];
+                    const bool h2 = slab(ro, rdInv[r], mk3(q0.z, q1.z, q2.z), mk3(q3.z, q4.z, q5.z), t2) && t2 <= tMax[r];
+                    const bool h3 = slab(ro, rdInv[r], mk3(q0.w, q1.w, q2.w), mk3(q3.w, q4.w, q5.w), t3) && t3 <= tMax[r];
+                    cm0 |= (h0 ? 1u : 0u) << r; cm1 |= (h1 ? 1u : 0u) << r; cm2 |= (h2 ? 1u : 0u) << r; cm3 |= (h3 ? 1u : 0u) << r;
+                }
+                const uint32_t in = pm & alive;   // rays that entered this node and are still undecided
+                uint32_t nxt = 0;
+                auto take = [&](uint32_t cm, int ref) {
+                    cm &= in;
+                    if (cm == 0u) return;
+                    uint32_t e = pk_entry(cm, ref);
+                    if (pk_is_leaf(e) && leafE == 0u) { leafE = e; return; }
+                    if (nxt == 0u) { nxt = e; return; }
+                    if (!pk_is_leaf(e) && pk_is_leaf(nxt)) { const uint32_t t = nxt; nxt = e; e = t; }   // go on with the inner node, defer the leaf
+                    stk[sp * 64] = e;
+                    sp++;
+                };
+                take(cm0, (int)f2u(q6.x)); take(cm1, (int)f2u(q6.y)); take(cm2, (int)f2u(q6.z)); take(cm3, (int)f2u(q6.w));
+                if (nxt == 0u) pop_or_finish();
+                else cur = nxt;
+            }
+        }
+        // ---- leaves
+        if (active && leafE != 0u) {
+            const uint32_t v = leafE & 0x07ffffffu;
+            const int first = (int)(v >> 3), count = (int)(v & 7u) + 1;
+            uint32_t m = (leafE >> 28) & alive;
+            auto test_tri = [&](V3 v0, V3 e1, V3 e2) {
+                // tri_hit (rt_bvh.glsl:154-170) for every ray of the leaf's mask; tvec, qvec and dot(e2, qvec) do not depend on the direction
+                const V3 tvec = ro - v0;
+                const V3 qvec = cross(tvec, e1);
+                const float te = dot(e2, qvec);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const V3 pvec = cross(rd[r], e2);
+                    const float det = dot(e1, pvec);
+                    const float invDet = 1.0f / det;
+                    const float u = dot(tvec, pvec) * invDet;
+                    const float vv = dot(rd[r], qvec) * invDet;
+                    const float tt = te * invDet;
+                    const bool hit = !(__builtin_fabsf(det) < 1e-8f) && !(u < 0.0f || u > 1.0f) && !(vv < 0.0f || u + vv > 1.0f) && !(tt < eps || tt > tMax[r]);
+                    if (hit && ((m >> r) & 1u)) { occl |= 1u << r; alive &= ~(1u << r); m &= ~(1u << r); }
+                }
+            };
+            for (int i = 0; i + 2 <= count && m != 0u; i += 2) {
+                const v4f *tv = reinterpret_cast<const v4f *>(pairs + (size_t)(first + (i >> 1)) * 5);
+                gathers += 5u;
+                v4f r0 = tv[0], r1 = tv[1], r2 = tv[2], r3 = tv[3], r4 = tv[4];
+                pin(r0); pin(r1); pin(r2); pin(r3); pin(r4);
+                test_tri(mk3(r0.x, r0.y, r0.z), mk3(r0.w, r1.x, r1.y), mk3(r1.z, r1.w, r2.x));
+                if (m != 0u) test_tri(mk3(r2.y, r2.z, r2.w), mk3(r3.x, r3.y, r3.z), mk3(r3.w, r4.x, r4.y));
+            }
+            if ((count & 1) && m != 0u) {
+                const v4f *tv = reinterpret_cast<const v4f *>(pairs + (size_t)(first + (count >> 1)) * 5);
+                gathers += 3u;
+                v4f r0 = tv[0], r1 = tv[1], r2 = tv[2];
+                pin(r0); pin(r1); pin(r2);
+                test_tri(mk3(r0.x, r0.y, r0.z), mk3(r0.w, r1.x, r1.y), mk3(r1.z, r1.w, r2.x));
+            }
+            leafE = 0;
+            if (alive == 0u) retire();
+            else {
+                if (cur != 0u && pk_is_leaf(cur)) { leafE = cur; cur = 0; }   // a second leaf was waiting in `cur`
+                if (cur == 0u) pop_or_finish();
+            }
+        }
+    }
+    if (tally) {
+        unsigned long long t = traced;
+        for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+        if (lane == 0 && t) atomicAdd(tally, t);
+    }
+    if (gatherLoads) {
+        unsigned long long g = gathers;
+        for (int off = 32; off > 0; off >>= 1) g += __shfl_down(g, off, 64);
+        if (lane == 0 && g) atomicAdd(gatherLoads, g);
+    }
+}
+
 // ---- stage: post_primary -------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_post_primary(const DevFrame *__restrict__ fr, Targets tg, WaveBuf wb) {   // workgroup = kAppendBatch x 256 candidates
     const uint32_t n = wb.counts[0];
@@ -1082,6 +1318,22 @@ void launch_trace(hipStream_t st, int cus, int gridPct, int depth, const DevFram
     else       { if (leafb >= 4) go(k_trace<Src, ANY, 4, false>); else go(k_trace<Src, ANY, 2, false>); }
 }
 
+void launch_packets(hipStream_t st, int cus, int gridPct, int depth, const DevFrame *fr, const DevScene &hs, PacketSrc src, uint32_t *head, unsigned long long *tally,
+                    unsigned long long *gatherLoads, TraceTune tune) {
+    const int stack = std::max(4, hs.anyStack > 0 ? hs.anyStack : 3 * ((depth + 1) / 2));
+    const size_t ldsBytes = (size_t)256 * stack * 4;
+    thread_local std::map<std::pair<int, size_t>, int> occ;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int &perCU = occ[{dev, ldsBytes}];
+    if (perCU == 0) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_trace_packets, 256, ldsBytes) != hipSuccess || perCU < 1) perCU = 1;
+        perCU = std::min(perCU, 8);
+    }
+    const unsigned blocks = (unsigned)std::max(8, cus * perCU * gridPct / 100);
+    hipLaunchKernelGGL(k_trace_packets, dim3(blocks), dim3(256), ldsBytes, st, fr, hs.w4, hs.pairs, src, head, tally, gatherLoads, tune, stack);
+}
+
 }  // namespace
 
 // -------------------------------------------------------------------------------------------------
@@ -1130,6 +1382,9 @@ struct RtWave {
     unsigned long long *acc = nullptr;   // traced-ray tallies accumulated over frames
     unsigned long long *stats = nullptr; // RT_TRACE_STATS=1: 4 stages x 8 diagnostic sums
     uint32_t *hostHits = nullptr;        // pinned: the hit count of a batch that needs more than one chunk (read back once per batch)
+    bool packetAO = false;               // RT_PACKET_AO=1 (measured option, round 4): the AO rays of a hit traced as one packet (k_trace_packets) instead of one by one in the any-hit launch
+    hipStream_t shadeStream = nullptr;   // RT_CU_SPLIT: the shading kernels' stream (a CU-masked one), else null
+    hipEvent_t hopEv = nullptr;
     bool binGi = false;                  // RT_BIN_GI=1: bounce rays sorted by direction inside each workgroup of k_gen_direct (experiment)
     bool chunksFromSlots = false;        // RT_CHUNKS_FROM_SLOTS=1 (tests): launch the chunk loop for every pixel slot, as rounds 1-2 did
 };
@@ -1149,11 +1404,21 @@ RtWave *rt_wave_create(int cus, RtArenaPool *pool, int lane) {
     if (const char *e = getenv("RT_CHUNKS_FROM_SLOTS")) w->chunksFromSlots = atoi(e) != 0;
     if (const char *e = getenv("RT_QUAD_REFILL")) w->tune.quadRefill = atoi(e) != 0;
     if (const char *e = getenv("RT_COOP")) w->tune.coop = atoi(e);
-    if (const char *e = getenv("RT_BIN_GI")) w->binGi = atoi(e) != 0;   // quad-cooperative node fetch of the closest-hit launches (measured option)
+    if (const char *e = getenv("RT_BIN_GI")) w->binGi = atoi(e) != 0;
+    if (const char *e = getenv("RT_PACKET_AO")) w->packetAO = atoi(e) != 0;
+    (void)hipEventCreateWithFlags(&w->hopEv, hipEventDisableTiming);
+    if (const char *e = getenv("RT_CU_SPLIT")) {
+        const int k = std::max(1, std::min(7, atoi(e)));
+        uint32_t mask[8];
+        for (int i = 0; i < 8; ++i) { uint32_t m = 0; for (int b = 0; b < 32; ++b) if (((i * 32 + b) & 7) < k) m |= 1u << b; mask[i] = m; }
+        if (hipExtStreamCreateWithCUMask(&w->shadeStream, 8, mask) != hipSuccess) w->shadeStream = nullptr;
+    }   // quad-cooperative node fetch of the closest-hit launches (measured option)
     return w;
 }
 void rt_wave_destroy(RtWave *w) {
     if (!w) return;
+    if (w->shadeStream) (void)hipStreamDestroy(w->shadeStream);
+    if (w->hopEv) (void)hipEventDestroy(w->hopEv);
     if (w->frameArena) (void)hipFree(w->frameArena);
     if (w->chunkArena && !w->pool) (void)hipFree(w->chunkArena);
     if (w->resultArena) (void)hipFree(w->resultArena);
@@ -1258,13 +1523,13 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
     // cursor table (one set of sharded cursors per trace launch) and per-chunk bounce counters: grown when a small queue budget
     // cuts the frame into more chunks than seen so far (4K / 16 spp at RT_QUEUE_BUDGET_MB=128 is 491 chunks).  Both arrays are
     // only touched by this lane's stream, which is drained first.
-    if (1 + nChunks * 3 > w->launchCap || nChunks > w->chunkCap) {
+    if (1 + nChunks * 4 > w->launchCap || nChunks > w->chunkCap) {
         W_TRY(hipStreamSynchronize(st));
         if (w->counts) (void)hipFree(w->counts);
         if (w->heads) (void)hipFree(w->heads);
         w->counts = w->heads = nullptr;
         w->launchCap = w->chunkCap = 0;
-        const int lc = std::max(kMinLaunches, 1 + nChunks * 3), cc = std::max(4096, nChunks);
+        const int lc = std::max(kMinLaunches, 1 + nChunks * 4), cc = std::max(4096, nChunks);
         W_TRY(hipMalloc(&w->counts, (size_t)(64 + cc) * sizeof(uint32_t)));
         W_TRY(hipMalloc(&w->heads, (size_t)lc * kHeadWords * sizeof(uint32_t)));
         w->launchCap = lc; w->chunkCap = cc;
@@ -1272,7 +1537,7 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
     wb.counts = w->counts; wb.heads = w->heads;
 
     W_TRY(hipMemsetAsync(w->counts, 0, (size_t)(64 + nChunks) * sizeof(uint32_t), st));
-    W_TRY(hipMemsetAsync(w->heads, 0, (size_t)(1 + nChunks * 3) * kHeadWords * sizeof(uint32_t), st));
+    W_TRY(hipMemsetAsync(w->heads, 0, (size_t)(1 + nChunks * 4) * kHeadWords * sizeof(uint32_t), st));
     // Persistent grids smaller than what fits, for the two queue launches of a cache-resident scene: they run near the vector L1's access
     // rate (0.81 accesses per clock and CU, PMC), which four and a half workgroups per CU sustain as well as six, and the
     // registers left free let the shading kernels of the other frame lanes run beside them instead of waiting for a persistent grid to
@@ -1290,10 +1555,20 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
     const unsigned tilesFrame = (unsigned)std::max(host.g.nLocalTiles, 0);
     const unsigned tiles = tilesFrame * (unsigned)batch;
     if (tiles == 0) return RT_OK;
+    // EXPERIMENT (RT_CU_SPLIT=k): the shading kernels run on a second stream restricted to k eighths of the CUs, the traversal
+    // launches -- the lane's own stream, created with the complementary mask in rt_api.hip -- on the rest.  ss == st when the experiment is off.
+    hipStream_t ss = w->shadeStream ? w->shadeStream : st;
+    auto hop = [&](hipStream_t from, hipStream_t to) -> hipError_t {
+        if (from == to) return hipSuccess;
+        hipError_t e = hipEventRecord(w->hopEv, from);
+        return e != hipSuccess ? e : hipStreamWaitEvent(to, w->hopEv, 0);
+    };
+    W_TRY(hop(st, ss));
 
-    rt_stage_begin(ctx, ST_PRIMARY, st);
-    hipLaunchKernelGGL(k_primary, dim3((tiles + kAppendBatch - 1) / kAppendBatch), dim3(256), 0, st, dFrame, tg, wb);
-    rt_stage_end(ctx, ST_PRIMARY, 1, st);
+    rt_stage_begin(ctx, ST_PRIMARY, ss);
+    hipLaunchKernelGGL(k_primary, dim3((tiles + kAppendBatch - 1) / kAppendBatch), dim3(256), 0, ss, dFrame, tg, wb);
+    rt_stage_end(ctx, ST_PRIMARY, 1, ss);
+    W_TRY(hop(ss, st));
 
     rt_stage_begin(ctx, ST_TRACE_PRIMARY, st);
     PrimarySrc ps;
@@ -1304,9 +1579,11 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
     launch_trace<PrimarySrc, false>(st, w->cus, gridPctPrimary, treeDepth, dFrame, host.sc, ps, &wb.heads[0], w->acc + 2, w->acc + 8, tuneP, S ? S + 0 : nullptr);
     rt_stage_end(ctx, ST_TRACE_PRIMARY, 1, st);
 
-    rt_stage_begin(ctx, ST_POST_PRIMARY, st);
-    hipLaunchKernelGGL(k_post_primary, dim3((tiles + kAppendBatch - 1) / kAppendBatch), dim3(256), 0, st, dFrame, tg, wb);
-    rt_stage_end(ctx, ST_POST_PRIMARY, 1, st);
+    W_TRY(hop(st, ss));
+    rt_stage_begin(ctx, ST_POST_PRIMARY, ss);
+    hipLaunchKernelGGL(k_post_primary, dim3((tiles + kAppendBatch - 1) / kAppendBatch), dim3(256), 0, ss, dFrame, tg, wb);
+    rt_stage_end(ctx, ST_POST_PRIMARY, 1, ss);
+    W_TRY(hop(ss, st));
 
     // More than one chunk: the number of chunks that hold hits is known only on the device.  Launching the chunk loop for the upper
     // bound (rounds 1-2) costs little time -- the kernels of an empty chunk return at once -- but fills the launch statistics with
@@ -1326,25 +1603,40 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
     for (int c = 0; c < nChunks; ++c) {
         const uint32_t c0 = (uint32_t)((size_t)c * CH);
         const unsigned gridHS = (unsigned)((CH * (size_t)SPP + 255) / 256), gridH = (unsigned)((CH + 255) / 256);
-        rt_stage_begin(ctx, ST_GEN_DIRECT, st);
-        hipLaunchKernelGGL(k_gen_direct, dim3(gridHS), dim3(256), 0, st, dFrame, wb, c0);
-        rt_stage_end(ctx, ST_GEN_DIRECT, 1, st);
+        W_TRY(hop(st, ss));
+        rt_stage_begin(ctx, ST_GEN_DIRECT, ss);
+        hipLaunchKernelGGL(k_gen_direct, dim3(gridHS), dim3(256), 0, ss, dFrame, wb, c0);
+        rt_stage_end(ctx, ST_GEN_DIRECT, 1, ss);
+        W_TRY(hop(ss, st));
 
+        // AO rays: one packet per hit (k_trace_packets); the any-hit launch below then starts behind the A AO slots of queue 1
+        const bool pkAO = w->packetAO && A > 0;
+        if (pkAO) {
+            PacketSrc pk;
+            pk.o = wb.shO; pk.d = wb.shD; pk.tm = wb.shT; pk.occ = wb.occ1; pk.liveCount = &wb.counts[1]; pk.c0 = c0; pk.cap = wb.CH; pk.stride = wb.CH; pk.A = A; pk.nLive = 0;
+            rt_stage_begin(ctx, ST_TRACE_AO, st);
+            launch_packets(st, w->cus, gridPct, treeDepth, dFrame, host.sc, pk, &wb.heads[(size_t)(1 + c * 4 + 3) * kHeadWords], w->acc + 7, w->acc + 14, tune);
+            rt_stage_end(ctx, ST_TRACE_AO, 1, st);
+        }
+        const size_t skip = pkAO ? (size_t)A * CH : 0;
         QueueSrc q1;
-        q1.o = wb.shO; q1.d = wb.shD; q1.tm = wb.shT; q1.liveCount = &wb.counts[1]; q1.c0 = c0; q1.cap = wb.CH; q1.stride = wb.CH; q1.slots = (uint32_t)S1;
-        q1.outT = nullptr; q1.outTri = nullptr; q1.outOcc = wb.occ1;
+        q1.o = wb.shO + skip; q1.d = wb.shD + skip; q1.tm = wb.shT + skip; q1.liveCount = &wb.counts[1]; q1.c0 = c0; q1.cap = wb.CH; q1.stride = wb.CH;
+        q1.slots = (uint32_t)(S1 - (pkAO ? A : 0));
+        q1.outT = nullptr; q1.outTri = nullptr; q1.outOcc = wb.occ1 + skip;
         if (u.enableGI == 1) {
             // bounce rays first, then ONE any-hit launch over both shadow queues
             QueueSrc qg;
             qg.o = wb.giO; qg.d = wb.giD; qg.tm = wb.giL; qg.liveCount = &wb.counts[1]; qg.c0 = c0; qg.cap = wb.CH; qg.stride = wb.CH; qg.slots = (uint32_t)SPP;
             qg.outT = wb.giT; qg.outTri = wb.giTri; qg.outOcc = nullptr;
             rt_stage_begin(ctx, ST_TRACE_GI, st);
-            launch_trace<QueueSrc, false>(st, w->cus, gridPct, treeDepth, dFrame, host.sc, qg, &wb.heads[(size_t)(1 + c * 3 + 1) * kHeadWords], w->acc + 4, w->acc + 10, tune, S ? S + 32 : nullptr);
+            launch_trace<QueueSrc, false>(st, w->cus, gridPct, treeDepth, dFrame, host.sc, qg, &wb.heads[(size_t)(1 + c * 4 + 1) * kHeadWords], w->acc + 4, w->acc + 10, tune, S ? S + 32 : nullptr);
             rt_stage_end(ctx, ST_TRACE_GI, 1, st);
 
-            rt_stage_begin(ctx, ST_GEN_GI, st);
-            hipLaunchKernelGGL(k_gen_gi, dim3(gridHS), dim3(256), 0, st, dFrame, wb, c0, &wb.counts[64 + c]);
-            rt_stage_end(ctx, ST_GEN_GI, 1, st);
+            W_TRY(hop(st, ss));
+            rt_stage_begin(ctx, ST_GEN_GI, ss);
+            hipLaunchKernelGGL(k_gen_gi, dim3(gridHS), dim3(256), 0, ss, dFrame, wb, c0, &wb.counts[64 + c]);
+            rt_stage_end(ctx, ST_GEN_GI, 1, ss);
+            W_TRY(hop(ss, st));
 
             DualQueueSrc qq;
             qq.a = q1;
@@ -1352,18 +1644,20 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
             qq.b.stride = wb.CH * (uint32_t)SPP; qq.b.slots = 6u;
             qq.b.outT = nullptr; qq.b.outTri = nullptr; qq.b.outOcc = wb.occ2;
             rt_stage_begin(ctx, ST_TRACE_SHADOW, st);
-            launch_trace<DualQueueSrc, true>(st, w->cus, gridPct, treeDepth, dFrame, host.sc, qq, &wb.heads[(size_t)(1 + c * 3 + 0) * kHeadWords], w->acc + 3, w->acc + 9, tune, S ? S + 16 : nullptr);
+            launch_trace<DualQueueSrc, true>(st, w->cus, gridPct, treeDepth, dFrame, host.sc, qq, &wb.heads[(size_t)(1 + c * 4 + 0) * kHeadWords], w->acc + 3, w->acc + 9, tune, S ? S + 16 : nullptr);
             rt_stage_end(ctx, ST_TRACE_SHADOW, 1, st);
         } else {
             rt_stage_begin(ctx, ST_TRACE_SHADOW, st);
-            launch_trace<QueueSrc, true>(st, w->cus, gridPct, treeDepth, dFrame, host.sc, q1, &wb.heads[(size_t)(1 + c * 3 + 0) * kHeadWords], w->acc + 3, w->acc + 9, tune, S ? S + 16 : nullptr);
+            launch_trace<QueueSrc, true>(st, w->cus, gridPct, treeDepth, dFrame, host.sc, q1, &wb.heads[(size_t)(1 + c * 4 + 0) * kHeadWords], w->acc + 3, w->acc + 9, tune, S ? S + 16 : nullptr);
             rt_stage_end(ctx, ST_TRACE_SHADOW, 1, st);
         }
         // the last traversal launch of the batch is queued: the shared ray arena may go to the next batch (k_combine reads the lane's own result arrays)
         if (w->pool && c == nChunks - 1) { W_TRY(hipEventRecord(w->pool->freeEv[w->arena], st)); w->pool->lastUser[w->arena] = st; }
-        rt_stage_begin(ctx, ST_COMBINE, st);
-        hipLaunchKernelGGL(k_combine, dim3(gridH), dim3(256), 0, st, dFrame, tg, wb, c0);
-        rt_stage_end(ctx, ST_COMBINE, 1, st);
+        W_TRY(hop(st, ss));
+        rt_stage_begin(ctx, ST_COMBINE, ss);
+        hipLaunchKernelGGL(k_combine, dim3(gridH), dim3(256), 0, ss, dFrame, tg, wb, c0);
+        rt_stage_end(ctx, ST_COMBINE, 1, ss);
+        W_TRY(hop(ss, st));
     }
     hipLaunchKernelGGL(k_accum_tally, dim3(1), dim3(64), 0, st, w->counts, w->acc, batch);
     // temporal resolve: the one stage that needs the previous frame's COLOR0 (and must not overtake its target stores)
