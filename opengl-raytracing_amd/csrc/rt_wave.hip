@@ -1460,41 +1460,70 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
     }
     // chunk capacity from the budget
     const size_t perHit = (size_t)(S1 + SPP + S2) * 36 + (size_t)S1 + (size_t)SPP * 12 + (size_t)S2;
-    size_t CH = std::min(nSlots, std::max<size_t>(w->budgetBytes / perHit, 4096));
-    CH = align_up(CH, 256);
+    const size_t CHbudget = align_up(std::min(nSlots, std::max<size_t>(w->budgetBytes / perHit, 4096)), 256);
     // ray records + liveness words (read by the traversal launches only: a SHARED arena can be handed on as soon as the last of them is done) ...
-    const size_t need = align_up(CH * (size_t)S1 * 32, 256) + align_up(CH * (size_t)SPP * 32, 256) + align_up(CH * (size_t)S2 * 32, 256) +
-                        align_up(CH * (size_t)S1 * 4, 256) + align_up(CH * (size_t)SPP * 4, 256) + align_up(CH * (size_t)S2 * 4, 256) + 4096;
+    auto rays_bytes = [&](size_t ch) {
+        return align_up(ch * (size_t)S1 * 32, 256) + align_up(ch * (size_t)SPP * 32, 256) + align_up(ch * (size_t)S2 * 32, 256) +
+               align_up(ch * (size_t)S1 * 4, 256) + align_up(ch * (size_t)SPP * 4, 256) + align_up(ch * (size_t)S2 * 4, 256) + 4096;
+    };
     // ... and the results k_combine reads (1 byte per any-hit ray, 8 per bounce ray, 4 per (hit, sample)): the lane's own
-    const size_t needRes = align_up(CH * (size_t)S1, 256) + align_up(CH * (size_t)SPP * 8, 256) + align_up(CH * (size_t)S2, 256) + align_up(CH * (size_t)SPP * 4, 256) * 2 + 4096;
-    if (w->resultBytes < needRes) {
-        if (w->resultArena) (void)hipFree(w->resultArena);
-        w->resultArena = nullptr;
-        w->resultBytes = 0;
-        W_TRY(hipMalloc(&w->resultArena, needRes));
-        w->resultBytes = needRes;
-    }
-    if (w->pool) {
-        // a shared arena: grown (never shrunk) once its current user is done with it
-        RtArenaPool &P = *w->pool;
-        const int a = w->arena;
-        if (P.bytes[a] < need) {
-            if (P.lastUser[a]) W_TRY(hipEventSynchronize(P.freeEv[a]));
-            if (P.mem[a]) (void)hipFree(P.mem[a]);
-            P.mem[a] = nullptr; P.bytes[a] = 0;
-            W_TRY(hipMalloc(&P.mem[a], need));
-            P.bytes[a] = need;
+    auto result_bytes = [&](size_t ch) {
+        return align_up(ch * (size_t)S1, 256) + align_up(ch * (size_t)SPP * 8, 256) + align_up(ch * (size_t)S2, 256) + align_up(ch * (size_t)SPP * 4, 256) * 2 + 4096;
+    };
+    // arrays that hold `ch` hits (grown, never shrunk; `room`: allocate for that many when growing, so that a batch with a few more hits fits too)
+    auto ensure = [&](size_t ch, size_t room) -> int {
+        if (w->resultBytes < result_bytes(ch)) {
+            if (w->resultArena) { W_TRY(hipStreamSynchronize(st)); (void)hipFree(w->resultArena); }
+            w->resultArena = nullptr;
+            w->resultBytes = 0;
+            W_TRY(hipMalloc(&w->resultArena, result_bytes(room)));
+            w->resultBytes = result_bytes(room);
         }
-        w->chunkArena = P.mem[a];
-    } else if (w->chunkBytes < need) {
-        if (w->chunkArena) (void)hipFree(w->chunkArena);
-        w->chunkArena = nullptr;
-        w->chunkBytes = 0;
-        W_TRY(hipMalloc(&w->chunkArena, need));
-        w->chunkBytes = need;
-    }
-    if (CH * (size_t)std::max(S1, S2) >= ((size_t)1 << 31)) { w->err = "ray queue chunk exceeds 2^31 entries; lower RT_QUEUE_BUDGET_MB"; return RT_ERR_UNSUPPORTED; }
+        if (w->pool) {
+            // a shared arena: grown once its current user is done with it
+            RtArenaPool &P = *w->pool;
+            const int a = w->arena;
+            if (P.bytes[a] < rays_bytes(ch)) {
+                if (P.lastUser[a]) W_TRY(hipEventSynchronize(P.freeEv[a]));
+                if (P.mem[a]) (void)hipFree(P.mem[a]);
+                P.mem[a] = nullptr; P.bytes[a] = 0;
+                W_TRY(hipMalloc(&P.mem[a], rays_bytes(room)));
+                P.bytes[a] = rays_bytes(room);
+            }
+            w->chunkArena = P.mem[a];
+        } else if (w->chunkBytes < rays_bytes(ch)) {
+            if (w->chunkArena) { W_TRY(hipStreamSynchronize(st)); (void)hipFree(w->chunkArena); }
+            w->chunkArena = nullptr;
+            w->chunkBytes = 0;
+            W_TRY(hipMalloc(&w->chunkArena, rays_bytes(room)));
+            w->chunkBytes = rays_bytes(room);
+        }
+        return RT_OK;
+    };
+    // Round 4: a launch set whose queues would be large if every pixel slot were a hit (a batch of eight 1080p frames: 30 GB) is sized from its HIT count --
+    // read back once, behind k_post_primary, on this lane's stream only (the other lanes keep the GPU busy: 1.726 vs 1.719 ms per frame with and without
+    // that read-back, profiles/r04_experiments.txt) -- instead of from the budget.  Small launch sets (and RT_CHUNKS_FROM_SLOTS) are sized from their pixel
+    // slots as before and never wait for the host.
+    constexpr size_t kComfortBytes = (size_t)4 << 30;
+    const bool deferred = !w->chunksFromSlots && rays_bytes(CHbudget) > kComfortBytes;
+    size_t CH = CHbudget;
     WaveBuf wb;
+    auto carve = [&](size_t ch) {
+        char *q = (char *)w->chunkArena;
+        auto take = [&](size_t bytes) { char *r = q; q += align_up(bytes, 256); return r; };
+        wb.shO = (float4 *)take(ch * (size_t)S1 * 16); wb.shD = (float4 *)take(ch * (size_t)S1 * 16);
+        wb.giO = (float4 *)take(ch * (size_t)SPP * 16); wb.giD = (float4 *)take(ch * (size_t)SPP * 16);
+        wb.sh2O = (float4 *)take(ch * (size_t)S2 * 16); wb.sh2D = (float4 *)take(ch * (size_t)S2 * 16);
+        wb.shT = (float *)take(ch * (size_t)S1 * 4); wb.giL = (float *)take(ch * (size_t)SPP * 4); wb.sh2T = (float *)take(ch * (size_t)S2 * 4);
+        q = (char *)w->resultArena;
+        wb.occ1 = (uint8_t *)take(ch * (size_t)S1);
+        wb.giT = (float *)take(ch * (size_t)SPP * 4); wb.giTri = (int *)take(ch * (size_t)SPP * 4);
+        wb.occ2 = (uint8_t *)take(ch * (size_t)S2);
+        wb.giPos = (int *)take(ch * (size_t)SPP * 4);
+        wb.giPerm = w->binGi ? (int *)take(ch * (size_t)SPP * 4) : nullptr;
+        wb.CH = (uint32_t)ch;
+    };
+    if (CHbudget * (size_t)std::max(S1, S2) >= ((size_t)1 << 31)) { w->err = "ray queue chunk exceeds 2^31 entries; lower RT_QUEUE_BUDGET_MB"; return RT_ERR_UNSUPPORTED; }
     {
         char *p = (char *)w->frameArena;
         wb.cand = (uint32_t *)p; p += nSlots * 4;
@@ -1505,18 +1534,13 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
         wb.pendPos = (uint2 *)p; p += nSlots * 8;
         wb.pendNrm = (uint2 *)p; p += nSlots * 8;
         wb.pendMy = (float *)p;
-        char *q = (char *)w->chunkArena;
-        auto take = [&](size_t bytes) { char *r = q; q += align_up(bytes, 256); return r; };
-        wb.shO = (float4 *)take(CH * (size_t)S1 * 16); wb.shD = (float4 *)take(CH * (size_t)S1 * 16);
-        wb.giO = (float4 *)take(CH * (size_t)SPP * 16); wb.giD = (float4 *)take(CH * (size_t)SPP * 16);
-        wb.sh2O = (float4 *)take(CH * (size_t)S2 * 16); wb.sh2D = (float4 *)take(CH * (size_t)S2 * 16);
-        wb.shT = (float *)take(CH * (size_t)S1 * 4); wb.giL = (float *)take(CH * (size_t)SPP * 4); wb.sh2T = (float *)take(CH * (size_t)S2 * 4);
-        q = (char *)w->resultArena;
-        wb.occ1 = (uint8_t *)take(CH * (size_t)S1);
-        wb.giT = (float *)take(CH * (size_t)SPP * 4); wb.giTri = (int *)take(CH * (size_t)SPP * 4);
-        wb.occ2 = (uint8_t *)take(CH * (size_t)S2);
-        wb.giPos = (int *)take(CH * (size_t)SPP * 4);
-        wb.giPerm = w->binGi ? (int *)take(CH * (size_t)SPP * 4) : nullptr;
+    }
+    wb.shO = wb.shD = wb.giO = wb.giD = wb.sh2O = wb.sh2D = nullptr; wb.shT = wb.giL = wb.sh2T = nullptr;   // (deferred: carved behind k_post_primary)
+    wb.occ1 = wb.occ2 = nullptr; wb.giT = nullptr; wb.giTri = wb.giPos = wb.giPerm = nullptr;
+    if (!deferred) {
+        int rc = ensure(CH, CH);
+        if (rc != RT_OK) return rc;
+        carve(CH);
     }
     wb.CH = (uint32_t)CH; wb.A = A; wb.SPP = SPP;
     int nChunks = (int)((nSlots + CH - 1) / CH);   // upper bound (every pixel slot a hit); cut down to the hit count below
@@ -1590,13 +1614,19 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
     // empty launches (bench.py's batches of eight 1080p frames: 5 launch sets, 2 of them with rays).  Such a batch is tens of
     // milliseconds of work, so the hit count is read back once (this lane's stream only; the other lanes keep the GPU busy) and
     // the hits are dealt over equal chunks.  A single-chunk frame -- every frame-by-frame BASELINE configuration -- never syncs.
-    if (nChunks > 1 && !w->chunksFromSlots) {
+    if ((deferred || nChunks > 1) && !w->chunksFromSlots) {
         if (!w->hostHits) W_TRY(hipHostMalloc((void **)&w->hostHits, sizeof(uint32_t)));
         W_TRY(hipMemcpyAsync(w->hostHits, &w->counts[1], sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         W_TRY(hipStreamSynchronize(st));
         const size_t hits = *w->hostHits;
-        nChunks = (int)((hits + CH - 1) / CH);
-        if (nChunks > 0) { CH = align_up((hits + (size_t)nChunks - 1) / (size_t)nChunks, 256); wb.CH = (uint32_t)CH; }
+        nChunks = (int)((hits + CHbudget - 1) / CHbudget);
+        if (nChunks > 0) CH = align_up((hits + (size_t)nChunks - 1) / (size_t)nChunks, 256);
+        if (deferred && nChunks > 0) {
+            // the arenas hold this launch set's hits (+ 6 % when they have to grow, at most what the budget allows)
+            int rc = ensure(CH, std::min(CHbudget, align_up(CH + CH / 16, 256)));
+            if (rc != RT_OK) return rc;
+        }
+        if (nChunks > 0) carve(CH);
     }
     // shared arena: everything from here to the last combine reads or writes it
     if (w->pool && nChunks > 0 && w->pool->lastUser[w->arena] && w->pool->lastUser[w->arena] != st) W_TRY(hipStreamWaitEvent(st, w->pool->freeEv[w->arena], 0));
