@@ -461,7 +461,7 @@ RT_DEV uint32_t quad_distinct(uint32_t key) {
 constexpr uint32_t kShards = 64, kShardStride = 32;   // cursor shards per trace launch, uint32 words between them (128 B)
 constexpr uint32_t kHeadWords = kShards * kShardStride;
 
-struct TraceTune { int refillMin; int minSearch; int chunk; int leafb; int skipTraversal; int quadRefill; int coop; int leafbClosest; };   // skipTraversal: diagnostic (RT_DEBUG_SKIP_TRAVERSAL)
+struct TraceTune { int refillMin; int minSearch; int chunk; int leafb; int skipTraversal; int quadRefill; int coop; int leafbClosest; int nearFirst; };   // skipTraversal: diagnostic (RT_DEBUG_SKIP_TRAVERSAL)
 
 template <bool ANY> struct StackOf { typedef StackEntry type; };          // closest: {deferred child, its entry distance}
 template <> struct StackOf<true> { typedef uint32_t type; };              // any-hit: the pop-time cull never fires (tMax is constant)
@@ -472,8 +472,8 @@ template <> struct StackOf<true> { typedef uint32_t type; };              // any
 extern __shared__ __align__(16) unsigned char rt_dyn_lds[];
 // Register budget: the closest-hit launches run five workgroups per CU (their 8-byte stack entries fill the LDS first), so their kernels may use
 // up to 96 VGPRs (five waves per SIMD) but not more; the diagnostic builds are unconstrained.
-template <class Src, bool ANY, int LEAFB, bool STATS = false, bool COOP = false>
-__global__ __launch_bounds__(256, (!STATS && !ANY) ? 5 : 1) void k_trace(const DevFrame *__restrict__ fr, const float4 *__restrict__ wnodes, const float4 *__restrict__ tris, Src src,
+template <class Src, bool ANY, int LEAFB, bool STATS = false, bool COOP = false, bool NEAR = false>
+__global__ __launch_bounds__(256, (!STATS && !ANY) ? 5 : (NEAR ? 6 : 1)) void k_trace(const DevFrame *__restrict__ fr, const float4 *__restrict__ wnodes, const float4 *__restrict__ tris, Src src,
                                                 uint32_t *head, unsigned long long *tally, unsigned long long *gatherLoads, TraceTune tune,
                                                 int stackEntries, unsigned long long *stats = nullptr) {
     // STATS (diagnostic build only, RT_TRACE_STATS=1): [0] inner-node visits [1] leaf visits [2] triangle tests [3] inner-phase wave
@@ -687,6 +687,20 @@ __global__ __launch_bounds__(256, (!STATS && !ANY) ? 5 : 1) void k_trace(const D
                         stk[sp * 64] = (uint32_t)r;
                         sp++;
                     };
+                    if constexpr (NEAR) {
+                        // RT_NEAR_FIRST=1 (experiment, round 4): go on with the NEAREST inner child that was hit instead of the first in record order -- an
+                        // occluded ray then tends to meet its occluder sooner; the answer (an OR over leaves) does not depend on the order
+                        float kb = h0 && r0 >= 0 ? t0 : 3.0e38f;
+                        int ib = 0;
+                        const float k1 = h1 && r1 >= 0 ? t1 : 3.0e38f, k2 = h2 && r2 >= 0 ? t2 : 3.0e38f, k3 = h3 && r3 >= 0 ? t3 : 3.0e38f;
+                        if (k1 < kb) { kb = k1; ib = 1; }
+                        if (k2 < kb) { kb = k2; ib = 2; }
+                        if (k3 < kb) { kb = k3; ib = 3; }
+                        if (ib == 1) { const bool th = h0; h0 = h1; h1 = th; const int tr_ = r0; r0 = r1; r1 = tr_; }
+                        if (ib == 2) { const bool th = h0; h0 = h2; h2 = th; const int tr_ = r0; r0 = r2; r2 = tr_; }
+                        if (ib == 3) { const bool th = h0; h0 = h3; h3 = th; const int tr_ = r0; r0 = r3; r3 = tr_; }
+                        // (a leaf child in position 0 goes to `leaf` or the stack as before: `take` prefers inner nodes for nxt)
+                    }
                     take(h0, r0); take(h1, r1); take(h2, r2); take(h3, r3);
                     if (nxt == RT_NO_CHILD) pop_or_finish();
                     else ref = nxt;
@@ -1315,6 +1329,7 @@ void launch_trace(hipStream_t st, int cus, int gridPct, int depth, const DevFram
     const int leafb = ANY ? tune.leafb : tune.leafbClosest;
     if (stats) { if (leafb >= 4) go(k_trace<Src, ANY, 4, true>); else go(k_trace<Src, ANY, 2, true>); }
     else if (!ANY && tune.coop) go(k_trace<Src, ANY, 2, false, !ANY>);
+    else if (ANY && tune.nearFirst) go(k_trace<Src, ANY, 2, false, false, ANY>);
     else       { if (leafb >= 4) go(k_trace<Src, ANY, 4, false>); else go(k_trace<Src, ANY, 2, false>); }
 }
 
@@ -1371,7 +1386,7 @@ struct RtWave {
     // ray-queue budget per frame lane; 288 GB of HBM make this cheap.  16 GB hold the queues of a whole batch of eight 1080p / 4 spp frames (7.4 M hits x
     // 2.1 KB) in ONE chunk: no hit-count read-back, half the launches (1.76-1.80 -> 1.68-1.72 ms per frame against 8 GB; profiles/r03_experiments.txt)
     size_t budgetBytes = (size_t)16 << 30;
-    TraceTune tune{32, 16, 0, 2, 0, 0, 0, 2};   // chunk 0 = run length chosen in the kernel from the queue size
+    TraceTune tune{32, 16, 0, 2, 0, 0, 0, 2, 0};   // chunk 0 = run length chosen in the kernel from the queue size
     // allocations
     size_t slotsCap = 0;      // per-frame arrays sized for this many pixel slots
     size_t chunkBytes = 0;    // bytes of the per-chunk arena
@@ -1405,6 +1420,7 @@ RtWave *rt_wave_create(int cus, RtArenaPool *pool, int lane) {
     if (const char *e = getenv("RT_QUAD_REFILL")) w->tune.quadRefill = atoi(e) != 0;
     if (const char *e = getenv("RT_COOP")) w->tune.coop = atoi(e);
     if (const char *e = getenv("RT_BIN_GI")) w->binGi = atoi(e) != 0;
+    if (const char *e = getenv("RT_NEAR_FIRST")) w->tune.nearFirst = atoi(e);
     if (const char *e = getenv("RT_PACKET_AO")) w->packetAO = atoi(e) != 0;
     (void)hipEventCreateWithFlags(&w->hopEv, hipEventDisableTiming);
     if (const char *e = getenv("RT_CU_SPLIT")) {
@@ -1705,14 +1721,14 @@ void rt_wave_trace_closest_indexed(hipStream_t st, int cus, int treeDepth, const
                                    const uint32_t *count, const float4 *o, const float4 *d, float *outT, int *outTri, uint32_t *heads) {
     IndexedSrc q;
     q.idx = idx; q.count = count; q.o = o; q.d = d; q.outT = outT; q.outTri = outTri; q.n = 0;
-    TraceTune tune{32, 16, 0, 2, 0, 0, 0, 2};
+    TraceTune tune{32, 16, 0, 2, 0, 0, 0, 2, 0};
     launch_trace<IndexedSrc, false>(st, cus, 100, treeDepth, dFrame, hostScene, q, heads, nullptr, nullptr, tune, nullptr);
 }
 void rt_wave_trace_closest_compact(hipStream_t st, int cus, int treeDepth, const DevFrame *dFrame, const DevScene &hostScene, const float4 *o, const float4 *d,
                                    const uint32_t *dst, const uint32_t *count, const uint32_t *flags, uint32_t cap, float *outT, int *outTri, uint32_t *heads) {
     CompactSrc q;
     q.o = o; q.d = d; q.dst = dst; q.count = count; q.flags = flags; q.cap = cap; q.outT = outT; q.outTri = outTri; q.n = 0;
-    TraceTune tune{32, 16, 0, 2, 0, 0, 0, 2};
+    TraceTune tune{32, 16, 0, 2, 0, 0, 0, 2, 0};
     launch_trace<CompactSrc, false>(st, cus, 100, treeDepth, dFrame, hostScene, q, heads, nullptr, nullptr, tune, nullptr);
 }
 size_t rt_wave_head_words() { return kHeadWords; }
