@@ -1367,21 +1367,22 @@ struct RtArenaPool {
 RtArenaPool *rt_arena_pool_create(int arenas) {
     RtArenaPool *p = new RtArenaPool();
     p->n = std::max(1, std::min(arenas, (int)RT_MAX_LANES));
-    for (int i = 0; i < p->n; ++i) (void)hipEventCreateWithFlags(&p->freeEv[i], hipEventDisableTiming);
+    for (int i = 0; i < RT_MAX_LANES; ++i) (void)hipEventCreateWithFlags(&p->freeEv[i], hipEventDisableTiming);
     return p;
 }
 void rt_arena_pool_destroy(RtArenaPool *p) {
     if (!p) return;
-    for (int i = 0; i < p->n; ++i) { if (p->mem[i]) (void)hipFree(p->mem[i]); if (p->freeEv[i]) (void)hipEventDestroy(p->freeEv[i]); }
+    for (int i = 0; i < RT_MAX_LANES; ++i) { if (p->mem[i]) (void)hipFree(p->mem[i]); if (p->freeEv[i]) (void)hipEventDestroy(p->freeEv[i]); }
     delete p;
 }
-int rt_arena_pool_count(const RtArenaPool *p) { return p ? p->n : 0; }
-size_t rt_arena_pool_bytes(const RtArenaPool *p) { size_t b = 0; for (int i = 0; p && i < p->n; ++i) b += p->bytes[i]; return b; }
+int rt_arena_pool_count(const RtArenaPool *p) { int c = 0; for (int i = 0; p && i < RT_MAX_LANES; ++i) c += p->mem[i] ? 1 : 0; return c; }
+size_t rt_arena_pool_bytes(const RtArenaPool *p) { size_t b = 0; for (int i = 0; p && i < RT_MAX_LANES; ++i) b += p->bytes[i]; return b; }
 
 struct RtWave {
     std::string err;
     RtArenaPool *pool = nullptr;   // null: this lane owns its arena (chunkArena below)
-    int arena = 0;                 // index into pool
+    int arena = 0;                 // index into pool: lane % n for a launch set of one chunk, the lane itself for a set of several (see rt_wave_render)
+    int lane = 0;
     int cus = 256;
     // ray-queue budget per frame lane; 288 GB of HBM make this cheap.  16 GB hold the queues of a whole batch of eight 1080p / 4 spp frames (7.4 M hits x
     // 2.1 KB) in ONE chunk: no hit-count read-back, half the launches (1.76-1.80 -> 1.68-1.72 ms per frame against 8 GB; profiles/r03_experiments.txt)
@@ -1408,6 +1409,7 @@ RtWave *rt_wave_create(int cus, RtArenaPool *pool, int lane) {
     RtWave *w = new RtWave();
     w->cus = cus > 0 ? cus : 256;
     w->pool = pool;
+    w->lane = lane;
     w->arena = pool ? lane % pool->n : 0;
     if (const char *e = getenv("RT_QUEUE_BUDGET_MB")) w->budgetBytes = (size_t)atoll(e) << 20;
     if (const char *e = getenv("RT_REFILL_MIN")) w->tune.refillMin = std::max(1, std::min(64, atoi(e)));
@@ -1554,6 +1556,7 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
     wb.shO = wb.shD = wb.giO = wb.giD = wb.sh2O = wb.sh2D = nullptr; wb.shT = wb.giL = wb.sh2T = nullptr;   // (deferred: carved behind k_post_primary)
     wb.occ1 = wb.occ2 = nullptr; wb.giT = nullptr; wb.giTri = wb.giPos = wb.giPerm = nullptr;
     if (!deferred) {
+        if (w->pool) w->arena = (nSlots + CH - 1) / CH > 1 ? w->lane : w->lane % w->pool->n;
         int rc = ensure(CH, CH);
         if (rc != RT_OK) return rc;
         carve(CH);
@@ -1637,6 +1640,10 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
         const size_t hits = *w->hostHits;
         nChunks = (int)((hits + CHbudget - 1) / CHbudget);
         if (nChunks > 0) CH = align_up((hits + (size_t)nChunks - 1) / (size_t)nChunks, 256);
+        // a set of several chunks keeps its arena for the whole chunk loop -- shared by two lanes that would serialise the lanes (4 spp -> 16 spp, 4K and
+        // the 1 M-triangle scene lost 3 % that way) -- so it takes the lane's OWN arena; one-chunk sets (every frame-by-frame configuration, bench.py's
+        // batches) share lane % n
+        if (w->pool && deferred) w->arena = nChunks > 1 ? w->lane : w->lane % w->pool->n;   // (not deferred: chosen and allocated before k_primary)
         if (deferred && nChunks > 0) {
             // the arenas hold this launch set's hits (+ 6 % when they have to grow, at most what the budget allows)
             int rc = ensure(CH, std::min(CHbudget, align_up(CH + CH / 16, 256)));
