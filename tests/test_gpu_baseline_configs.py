@@ -327,6 +327,45 @@ def test_batched_frames_with_chunked_queues_against_the_oracle(from_slots):
     assert "BATCH-CHUNKED-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_config4_scene_spp_and_accumulation_together(orc):
+    """BASELINE configs[4] with its three dimensions TOGETHER (they had only run one at a time): the 1 M-triangle multi-object
+    scene, 64 spp, temporal accumulation over 32 frames -- at 192x120 (the oracle's cost is per pixel, sample and frame), rendered in batches of eight
+    through rt_render_frames (32 frames = four batches; the history weight switches at frames 8 and 32; one launch set = 8 x 64 samples per hit, several
+    chunks of the default queue budget are NOT needed at this size, the deep tree's 24- / 36-entry stacks are) -- against the oracle on a 24x12 window
+    with the whole 32-frame history chain, and wavefront == frame-by-frame rendering on all four full targets."""
+    v, f = rt.meshgen.million_triangle_scene()
+    nodes, tris = rt.build_bvh(rt.gather_triangles(v, f, np.eye(4, dtype=np.float32).reshape(-1)))
+    assert tris.shape[0] == 1_000_000
+    faces = scenes.tiny_env(16)
+    W, H, FRAMES = 192, 120, 32
+    p = rt.default_render_params()
+    p.sppPerFrame = 64
+    cam = scenes.camera("default", aspect=W / H)
+    us = [rt.frame_uniforms(p, cam, W, H, f_, True, nodes.shape[0], tris.shape[0]) for f_ in range(FRAMES)]
+    with rt.Renderer() as many, rt.Renderer() as one:
+        for r in (many, one):
+            r.upload_bvh(nodes, tris)
+            r.upload_env(faces)
+            r.resize(W, H)
+        for b in range(0, FRAMES, 8):
+            many.render_frames(us[b:b + 8])
+        for u in us:
+            one.render_frame(u)
+        got = many.read_all()
+        for a, b in zip(got, one.read_all()):
+            assert np.array_equal(a, b)
+        assert many.traced_rays().hitPixels > FRAMES * 1000
+    x0, y0 = 84, 54
+    x1, y1 = x0 + 24, y0 + 12
+    prev = None
+    for u in us:
+        want, _ = orc.render(u, nodes, tris, faces, prev, region=(x0, y0, x1, y1), nthreads=16)
+        prev = want[0]
+    assert want[2][y0:y1, x0:x1].any()          # the window shows geometry
+    for g, w_ in zip(got, want):
+        assert np.array_equal(g[y0:y1, x0:x1], w_[y0:y1, x0:x1])
+
+
 def test_mixed_sequences_fall_back_per_run(orc):
     """rt_render_frames decides batching per run of frames, not once from the first frame -- [BVH, analytic, analytic, BVH, BVH]
     renders (the analytic frames one by one on the megakernel) instead of failing with "a frame batch reached the megakernel" after frame 0."""
