@@ -124,6 +124,7 @@ int main(int argc, char **argv) {
     float dt = 1.0f / 60.0f;   // seconds per frame for the point-light orbit
     int W = 1920, H = 1080, frames = 1, device = 0, useBVH = 0, showMotion = 0;
     int giBounces = 1;
+    int envFilter = 0;   // RtExtension.envFilter: 0 = bilinear weights in exact fp32, 1 = texel coordinates rounded to 1/256 texel
     int ranks = 0, gatherEvery = 1;          // ranks 0 = plain single-process run without a communicator
     bool dryRun = false;                     // --dry-run: fork + id hand-over only, nothing touches a GPU (rehearsal of the launcher on any host)
     std::vector<int> devices;
@@ -155,6 +156,7 @@ int main(int argc, char **argv) {
                 else if (k == "bvh") useBVH = v.num != 0;
                 else if (k == "hybrid") { if (v.num != 0) useBVH = RT_SCENE_HYBRID; }
                 else if (k == "giBounces") giBounces = (int)v.num;
+                else if (k == "envFilter") envFilter = (int)v.num;
                 else if (k == "motion") showMotion = v.num != 0;
                 else if (k == "camera") {
                     ok = v.kind == scenefile::Value::Obj;
@@ -187,6 +189,7 @@ int main(int argc, char **argv) {
         else if (a == "--analytic") useBVH = 0;
         else if (a == "--hybrid") useBVH = RT_SCENE_HYBRID;          // EXTENSION: analytic scene + the mesh (include/rt_mi355.h)
         else if (a == "--gi-bounces") giBounces = std::atoi(next());  // EXTENSION: bounces of the analytic / hybrid GI path
+        else if (a == "--env-filter") envFilter = std::atoi(next());  // cube-map filter model (RtExtension.envFilter)
         else if (a == "--motion") showMotion = 1;
         else if (a == "--no-gi") params.enableGI = 0;
         else if (a == "--no-ao") params.enableAO = 0;
@@ -200,6 +203,7 @@ int main(int argc, char **argv) {
         else { std::fprintf(stderr, "usage: rt_cli [--obj f.obj] [--env cross.png] [--size WxH] [--spp n] [--frames n] [--bvh|--analytic] [--motion]\n"
                                     "              [--cam x,y,z,yaw,pitch] [--fov deg] [--aspect a] [--exposure e] [--no-gi --no-ao --no-taa --no-svgf --no-env] [--out prefix]\n"
                                     "              [--hybrid [--gi-bounces n]]   EXTENSION: the analytic scene with the .obj mesh added to it, n diffuse GI bounces\n"
+                                    "              [--env-filter 0|1]   cube-map filter model: exact fp32 weights (default) / texel coordinates rounded to 1/256 texel\n"
                                     "              [--ranks N [--devices d0,d1,..] [--gather-every k] [--dry-run]]   tile-parallel over N GPUs, one process each, RCCL gather to rank 0\n"
                                     "              (--obj may be repeated; --dump-targets writes prefix_{color,motion,gpos,gnrm}.pfm; --scene file.json sets any of\n"
                                     "               the above and every RenderParams field by name)\n"); return a == "--help" ? 0 : 2; }
@@ -320,7 +324,7 @@ int main(int argc, char **argv) {
         else RT_SAY("[ENV] %s: 6 x %dx%d\n", env.c_str(), n, n);
     }
     if ((rc = rt_resize(ctx, W, H)) != RT_OK) die(ctx, "rt_resize", rc);
-    if (giBounces != 1) { RtExtension ext{}; ext.giBounces = giBounces; if ((rc = rt_set_extension(ctx, &ext)) != RT_OK) die(ctx, "rt_set_extension", rc); }
+    if (giBounces != 1 || envFilter != 0) { RtExtension ext{}; ext.giBounces = giBounces; ext.envFilter = envFilter; if ((rc = rt_set_extension(ctx, &ext)) != RT_OK) die(ctx, "rt_set_extension", rc); }
 
     const auto t0 = std::chrono::steady_clock::now();
     const bool lightMoving = params.pointLightOrbitEnabled != 0 && std::fabs(params.pointLightOrbitSpeed) > 1e-5f && params.pointLightOrbitRadius > 0.0f;

@@ -1645,8 +1645,10 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
         // batches) share lane % n
         if (w->pool && deferred) w->arena = nChunks > 1 ? w->lane : w->lane % w->pool->n;   // (not deferred: chosen and allocated before k_primary)
         if (deferred && nChunks > 0) {
-            // the arenas hold this launch set's hits (+ 6 % when they have to grow, at most what the budget allows)
-            int rc = ensure(CH, std::min(CHbudget, align_up(CH + CH / 16, 256)));
+            // the arenas hold this launch set's hits (+ 6 % when they have to grow); a set of several chunks gets the whole budget at once: its chunk size
+            // changes with the number of frames in the batch (20 M hits = 3 x 6.7 M, 17 M = 2 x 8.6 M), and growing a 16 GB arena in the middle of a run
+            // is a device-wide synchronisation plus a large allocation (the 1 M-triangle scene at --steps 20: 47.6 instead of 18.7 ms per frame)
+            int rc = ensure(CH, nChunks > 1 ? CHbudget : std::min(CHbudget, align_up(CH + CH / 16, 256)));
             if (rc != RT_OK) return rc;
         }
         if (nChunks > 0) carve(CH);
