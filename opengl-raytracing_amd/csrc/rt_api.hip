@@ -668,6 +668,35 @@ int rt_upload_bvh(RtContext *c, const float *nodes12, int nNodes, const float *t
         }
         if (3 * depth4 <= 60) { w4.swap(s4); rootRef4 = 0; anyStack = 3 * depth4; }
     }
+    // Exact stack need of the any-hit walk (round 4): a visit of a node with nc children pushes at most nc - 1 entries (one child is gone on with),
+    // so S(node) = nc - 1 + max over its inner children S(child).  Round 3 sized the stack as 3 per two binary levels INCLUDING the leaf level: 24 entries
+    // for the bench mesh, where 21 are enough -- and 21 x 4 B x 256 threads let seven workgroups share a CU's 160 KB of LDS instead of six.
+    if (rootRef4 == 0 && w4.size() >= 32) {
+        const size_t n4 = w4.size() / 32;
+        std::vector<int> need(n4, -1);
+        std::vector<std::pair<size_t, int>> st{{0, 0}};   // (node, next child to look at)
+        while (!st.empty()) {
+            auto &[nn, ci] = st.back();
+            if (ci < 4) {
+                int ref;
+                std::memcpy(&ref, &w4[nn * 32 + 24 + (size_t)ci], 4);
+                ++ci;
+                if (ref >= 0 && ref != RT_NO_CHILD && (size_t)ref < n4 && need[(size_t)ref] < 0) st.push_back({(size_t)ref, 0});
+                continue;
+            }
+            int nc = 0, deepest = 0;
+            for (int i = 0; i < 4; ++i) {
+                int ref;
+                std::memcpy(&ref, &w4[nn * 32 + 24 + (size_t)i], 4);
+                if (ref == RT_NO_CHILD) continue;
+                ++nc;
+                if (ref >= 0 && (size_t)ref < n4) deepest = std::max(deepest, need[(size_t)ref]);
+            }
+            need[nn] = std::max(nc - 1, 0) + deepest;
+            st.pop_back();
+        }
+        anyStack = std::max(need[0], 1);
+    }
     if (depth > 32) return fail(c, RT_ERR_UNSUPPORTED, "rt_upload_bvh: tree depth %d exceeds the 32-entry traversal stack", depth);
     HIP_TRY(c, hipMalloc(&c->dWNodes, wn.size() * sizeof(float)));
     HIP_TRY(c, hipMalloc(&c->dW4, w4.size() * sizeof(float)));

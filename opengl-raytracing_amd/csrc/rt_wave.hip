@@ -472,8 +472,11 @@ template <> struct StackOf<true> { typedef uint32_t type; };              // any
 extern __shared__ __align__(16) unsigned char rt_dyn_lds[];
 // Register budget: the closest-hit launches run five workgroups per CU (their 8-byte stack entries fill the LDS first), so their kernels may use
 // up to 96 VGPRs (five waves per SIMD) but not more; the diagnostic builds are unconstrained.
+#ifndef RT_ANYHIT_WAVES
+#define RT_ANYHIT_WAVES 7   // any-hit launches: 72 VGPRs, seven waves per SIMD (with the exact stack size of rt_upload_bvh seven workgroups fit a CU's LDS)
+#endif
 template <class Src, bool ANY, int LEAFB, bool STATS = false, bool COOP = false, bool NEAR = false>
-__global__ __launch_bounds__(256, (!STATS && !ANY) ? 5 : (NEAR ? 6 : 1)) void k_trace(const DevFrame *__restrict__ fr, const float4 *__restrict__ wnodes, const float4 *__restrict__ tris, Src src,
+__global__ __launch_bounds__(256, (!STATS && !ANY) ? 5 : (NEAR ? 6 : (ANY && !STATS && LEAFB == 2 ? RT_ANYHIT_WAVES : 1))) void k_trace(const DevFrame *__restrict__ fr, const float4 *__restrict__ wnodes, const float4 *__restrict__ tris, Src src,
                                                 uint32_t *head, unsigned long long *tally, unsigned long long *gatherLoads, TraceTune tune,
                                                 int stackEntries, unsigned long long *stats = nullptr) {
     // STATS (diagnostic build only, RT_TRACE_STATS=1): [0] inner-node visits [1] leaf visits [2] triangle tests [3] inner-phase wave
