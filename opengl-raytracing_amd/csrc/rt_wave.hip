@@ -497,8 +497,9 @@ __global__ __launch_bounds__(256, (!STATS && !ANY) ? 5 : (NEAR ? 6 : (ANY && !ST
     // run length: RT_CHUNK, else about a third of a wave's share of the queue, in [128, 384] rays (measured on MI355X, 1080p / 4 spp:
     // whole frame 2.42 / 2.26 / 2.18 / 2.20 ms with runs of 64 / 128 / 256 / 512; one rank of eight 0.51 / 0.48 / 0.52 / 0.55; round 3, batches
     // of eight frames, 1.83 / 1.78 / 1.79 ms per frame with runs of at most 256 / 384 / 512)
+    // round 4 (seven-wave any-hit kernels, larger grids): at most 768 -- 1.669 against 1.678 / 1.695 / 1.70 ms per frame with runs of at most 512 / 384 / 1024
     const uint32_t runLen = tune.chunk > 0 ? (uint32_t)max(tune.chunk, 8)
-                                           : min(384u, max(128u, ((n / (3u * 4u * gridDim.x) + 63u) / 64u) * 64u));
+                                           : min(768u, max(128u, ((n / (3u * 4u * gridDim.x) + 63u) / 64u) * 64u));
 
     // per-lane ray state
     V3 ro = mk3(0.0f), rd = mk3(0.0f), rdInv = mk3(0.0f);
