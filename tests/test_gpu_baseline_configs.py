@@ -366,6 +366,35 @@ def test_config4_scene_spp_and_accumulation_together(orc):
         assert np.array_equal(g[y0:y1, x0:x1], w_[y0:y1, x0:x1])
 
 
+def test_shared_ray_arenas_and_memory_info(orc):
+    """Round 4: the ray-queue arenas are shared by the frame lanes (two for four lanes; a launch set of several chunks takes its lane's own) and
+    rt_get_memory_info reports them.  Twelve batches of four frames keep all four lanes and both arenas turning over; the last frame equals the
+    oracle's (11 batches of history), and the report is consistent: two arenas, four lanes, device figures from hipMemGetInfo."""
+    W, H, K, NB = 160, 96, 4, 12
+    nodes, tris = scenes.bunny_bvh(3)
+    faces = scenes.tiny_env(8)
+    p = rt.default_render_params()
+    p.sppPerFrame = 2
+    cam = scenes.camera("closeup", aspect=W / H)
+    us = [rt.frame_uniforms(p, cam, W, H, f, True, nodes.shape[0], tris.shape[0]) for f in range(K * NB)]
+    with rt.Renderer(pipeline=rt.RT_PIPELINE_WAVEFRONT) as r:
+        r.upload_bvh(nodes, tris)
+        r.upload_env(faces)
+        r.resize(W, H)
+        for b in range(NB):
+            r.render_frames(us[b * K:(b + 1) * K])      # no synchronisation in between: lanes and arenas overlap
+        got = r.read_all()
+        m = r.memory_info()
+    assert m.lanes == 4 and m.queueArenas == 2 and m.queueArenaBytes > 0 and m.frameArrayBytes > 0 and m.hybridArenaBytes == 0
+    assert 0 < m.deviceFreeBytes < m.deviceTotalBytes
+    prev = None
+    for u in us:
+        want, _ = orc.render(u, nodes, tris, faces, prev, nthreads=16)
+        prev = want[0]
+    for g, w_ in zip(got, want):
+        assert np.array_equal(g, w_)
+
+
 def test_mixed_sequences_fall_back_per_run(orc):
     """rt_render_frames decides batching per run of frames, not once from the first frame -- [BVH, analytic, analytic, BVH, BVH]
     renders (the analytic frames one by one on the megakernel) instead of failing with "a frame batch reached the megakernel" after frame 0."""
