@@ -385,8 +385,10 @@ def test_shared_ray_arenas_and_memory_info(orc):
             r.render_frames(us[b * K:(b + 1) * K])      # no synchronisation in between: lanes and arenas overlap
         got = r.read_all()
         m = r.memory_info()
-    assert m.lanes == 4 and m.queueArenas == 2 and m.queueArenaBytes > 0 and m.frameArrayBytes > 0 and m.hybridArenaBytes == 0
+    assert m.queueArenaBytes > 0 and m.frameArrayBytes > 0 and m.hybridArenaBytes == 0 and 1 <= m.queueArenas <= m.lanes
     assert 0 < m.deviceFreeBytes < m.deviceTotalBytes
+    if not any(k in os.environ for k in ("RT_LANES", "RT_ARENAS", "RT_QUEUE_BUDGET_MB", "RT_CHUNKS_FROM_SLOTS")):   # (tools/r04_stress.sh overrides them)
+        assert m.lanes == 4 and m.queueArenas == 2
     prev = None
     for u in us:
         want, _ = orc.render(u, nodes, tris, faces, prev, nthreads=16)
