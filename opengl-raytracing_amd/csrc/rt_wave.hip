@@ -461,7 +461,7 @@ RT_DEV uint32_t quad_distinct(uint32_t key) {
 constexpr uint32_t kShards = 64, kShardStride = 32;   // cursor shards per trace launch, uint32 words between them (128 B)
 constexpr uint32_t kHeadWords = kShards * kShardStride;
 
-struct TraceTune { int refillMin; int minSearch; int chunk; int leafb; int skipTraversal; int quadRefill; int coop; int leafbClosest; int nearFirst; };   // skipTraversal: diagnostic (RT_DEBUG_SKIP_TRAVERSAL)
+struct TraceTune { int refillMin; int minSearch; int chunk; int leafb; int skipTraversal; int quadRefill; int coop; int leafbClosest; int nearFirst; int reverse; int guided; };   // skipTraversal: diagnostic (RT_DEBUG_SKIP_TRAVERSAL)
 
 template <bool ANY> struct StackOf { typedef StackEntry type; };          // closest: {deferred child, its entry distance}
 template <> struct StackOf<true> { typedef uint32_t type; };              // any-hit: the pop-time cull never fires (tMax is constant)
@@ -515,7 +515,15 @@ __global__ __launch_bounds__(256, (!STATS && !ANY) ? 5 : (NEAR ? 6 : (ANY && !ST
     uint32_t runNext = 0, runEnd = 0;   // wave-uniform: the part of the current run not handed out yet
     const uint32_t shard = (blockIdx.x * 4u + (threadIdx.x >> 6)) % kShards;   // home shard of this wave
     bool homeDry = false;
-    const uint32_t nRuns = (n + runLen - 1u) / runLen;
+    // Guided run lengths (RT_GUIDED=1 / 2, measured option of round 4, off): the rays dealt LAST go out in short runs -- `lateRays` (about an eighth of the
+    // queue, a multiple of runLen) in runs of runLen / 8 (at least 64) -- so that the launch does not end with a few waves still working through a long run
+    // each.  Alone the bounce launch gains 2 %; with four launch sets in flight, which fill each other's tails anyway, the frame is 1-2 % slower
+    // (profiles/r04_experiments.txt 13).  Dealing order d = 0 .. nRuns - 1: the nEarly long runs first, then the short ones.
+    const bool guided = tune.guided == 1 || (tune.guided == 2 && !ANY);   // 2: closest-hit launches only
+    const uint32_t shortLen = guided ? max(64u, runLen / 8u) : runLen;
+    const uint32_t lateRays = (guided && n > 16u * runLen) ? (n / 8u / runLen) * runLen : 0u;
+    const uint32_t nEarly = (n - lateRays + runLen - 1u) / runLen;
+    const uint32_t nRuns = nEarly + (lateRays + shortLen - 1u) / shortLen;
 
     // pop the next subtree of this lane's ray, or retire the ray
     auto pop_or_finish = [&]() {
@@ -588,9 +596,22 @@ __global__ __launch_bounds__(256, (!STATS && !ANY) ? 5 : (NEAR ? 6 : (ANY && !ST
                     got = k < runsOf(from);           // lost a race for the last run of that shard: probe again
                 }
                 if (!got) { exhausted = true; continue; }
-                const unsigned long long base = ((unsigned long long)k * kShards + from) * runLen;
-                runNext = (uint32_t)base;
-                runEnd = (uint32_t)min((unsigned long long)n, base + runLen);
+                // any-hit queues are dealt from their END (round 4): the expensive rays -- bounce-hit shadow rays, then the disk / sun / point slots -- sit behind
+                // the cheap AO slots, and a launch that starts with its longest work ends with short runs instead of a tail of long ones
+                const uint32_t dIdx = k * kShards + from;           // place in the dealing order
+                const bool late = dIdx >= nEarly;
+                const uint32_t len = late ? shortLen : runLen;
+                const uint32_t span = late ? lateRays : n - lateRays;   // rays of the region this run belongs to
+                const uint32_t off = (late ? dIdx - nEarly : dIdx) * len;   // offset inside the region, in dealing order
+                const uint32_t cnt = min(len, span - off);
+                if (ANY && tune.reverse) {                          // region layout: [late | early], each dealt from its end
+                    const uint32_t top = late ? lateRays : n;
+                    runEnd = top - off;
+                    runNext = runEnd - cnt;
+                } else {                                            // [early | late], each dealt from its beginning
+                    runNext = (late ? n - lateRays : 0u) + off;
+                    runEnd = runNext + cnt;
+                }
             }
             // Deal the run's LIVE rays to the idle lanes, one 64-slot window per pass: every lane probes one slot's liveness word
             // (coalesced), the live slots go to the idle lanes in order and dead slots cost nothing further.  (Before, a refill
@@ -1391,7 +1412,7 @@ struct RtWave {
     // ray-queue budget per frame lane; 288 GB of HBM make this cheap.  16 GB hold the queues of a whole batch of eight 1080p / 4 spp frames (7.4 M hits x
     // 2.1 KB) in ONE chunk: no hit-count read-back, half the launches (1.76-1.80 -> 1.68-1.72 ms per frame against 8 GB; profiles/r03_experiments.txt)
     size_t budgetBytes = (size_t)16 << 30;
-    TraceTune tune{32, 16, 0, 2, 0, 0, 0, 2, 0};   // chunk 0 = run length chosen in the kernel from the queue size
+    TraceTune tune{32, 16, 0, 2, 0, 0, 0, 2, 0, 1, 0};   // chunk 0 = run length chosen in the kernel from the queue size
     // allocations
     size_t slotsCap = 0;      // per-frame arrays sized for this many pixel slots
     size_t chunkBytes = 0;    // bytes of the per-chunk arena
@@ -1427,6 +1448,8 @@ RtWave *rt_wave_create(int cus, RtArenaPool *pool, int lane) {
     if (const char *e = getenv("RT_COOP")) w->tune.coop = atoi(e);
     if (const char *e = getenv("RT_BIN_GI")) w->binGi = atoi(e) != 0;
     if (const char *e = getenv("RT_NEAR_FIRST")) w->tune.nearFirst = atoi(e);
+    if (const char *e = getenv("RT_REVERSE")) w->tune.reverse = atoi(e);
+    if (const char *e = getenv("RT_GUIDED")) w->tune.guided = atoi(e);     // 0: runs of one length, as in rounds 1-3   // 0: any-hit queues dealt from their beginning, as in rounds 1-3
     if (const char *e = getenv("RT_PACKET_AO")) w->packetAO = atoi(e) != 0;
     (void)hipEventCreateWithFlags(&w->hopEv, hipEventDisableTiming);
     if (const char *e = getenv("RT_CU_SPLIT")) {
@@ -1734,14 +1757,14 @@ void rt_wave_trace_closest_indexed(hipStream_t st, int cus, int treeDepth, const
                                    const uint32_t *count, const float4 *o, const float4 *d, float *outT, int *outTri, uint32_t *heads) {
     IndexedSrc q;
     q.idx = idx; q.count = count; q.o = o; q.d = d; q.outT = outT; q.outTri = outTri; q.n = 0;
-    TraceTune tune{32, 16, 0, 2, 0, 0, 0, 2, 0};
+    TraceTune tune{32, 16, 0, 2, 0, 0, 0, 2, 0, 1, 0};
     launch_trace<IndexedSrc, false>(st, cus, 100, treeDepth, dFrame, hostScene, q, heads, nullptr, nullptr, tune, nullptr);
 }
 void rt_wave_trace_closest_compact(hipStream_t st, int cus, int treeDepth, const DevFrame *dFrame, const DevScene &hostScene, const float4 *o, const float4 *d,
                                    const uint32_t *dst, const uint32_t *count, const uint32_t *flags, uint32_t cap, float *outT, int *outTri, uint32_t *heads) {
     CompactSrc q;
     q.o = o; q.d = d; q.dst = dst; q.count = count; q.flags = flags; q.cap = cap; q.outT = outT; q.outTri = outTri; q.n = 0;
-    TraceTune tune{32, 16, 0, 2, 0, 0, 0, 2, 0};
+    TraceTune tune{32, 16, 0, 2, 0, 0, 0, 2, 0, 1, 0};
     launch_trace<CompactSrc, false>(st, cus, 100, treeDepth, dFrame, hostScene, q, heads, nullptr, nullptr, tune, nullptr);
 }
 size_t rt_wave_head_words() { return kHeadWords; }
