@@ -461,7 +461,7 @@ RT_DEV uint32_t quad_distinct(uint32_t key) {
 constexpr uint32_t kShards = 64, kShardStride = 32;   // cursor shards per trace launch, uint32 words between them (128 B)
 constexpr uint32_t kHeadWords = kShards * kShardStride;
 
-struct TraceTune { int refillMin; int minSearch; int chunk; int leafb; int skipTraversal; int quadRefill; int coop; int leafbClosest; int nearFirst; int reverse; int guided; };   // skipTraversal: diagnostic (RT_DEBUG_SKIP_TRAVERSAL)
+struct TraceTune { int refillMin; int minSearch; int chunk; int leafb; int skipTraversal; int quadRefill; int coop; int leafbClosest; int nearFirst; int reverse; int guided; int chunkMax; };   // skipTraversal: diagnostic (RT_DEBUG_SKIP_TRAVERSAL)
 
 template <bool ANY> struct StackOf { typedef StackEntry type; };          // closest: {deferred child, its entry distance}
 template <> struct StackOf<true> { typedef uint32_t type; };              // any-hit: the pop-time cull never fires (tMax is constant)
@@ -498,8 +498,10 @@ __global__ __launch_bounds__(256, (!STATS && !ANY) ? 5 : (NEAR ? 6 : (ANY && !ST
     // whole frame 2.42 / 2.26 / 2.18 / 2.20 ms with runs of 64 / 128 / 256 / 512; one rank of eight 0.51 / 0.48 / 0.52 / 0.55; round 3, batches
     // of eight frames, 1.83 / 1.78 / 1.79 ms per frame with runs of at most 256 / 384 / 512)
     // round 4 (seven-wave any-hit kernels, larger grids): at most 768 -- 1.669 against 1.678 / 1.695 / 1.70 ms per frame with runs of at most 512 / 384 / 1024
+    // primary launch (chunkMax 256): runs of 64 candidates = one 8x8 pixel block were right for single frames traced alone (rounds 1-3); with batches of
+    // frames and four launch sets in flight 256 are: 1.613 against 1.640 ms per frame, frame by frame 1.805 against 1.825, one rank of eight 0.225 against 0.230
     const uint32_t runLen = tune.chunk > 0 ? (uint32_t)max(tune.chunk, 8)
-                                           : min(768u, max(128u, ((n / (3u * 4u * gridDim.x) + 63u) / 64u) * 64u));
+                                           : min((uint32_t)tune.chunkMax, max(128u, ((n / (3u * 4u * gridDim.x) + 63u) / 64u) * 64u));
 
     // per-lane ray state
     V3 ro = mk3(0.0f), rd = mk3(0.0f), rdInv = mk3(0.0f);
@@ -1412,7 +1414,7 @@ struct RtWave {
     // ray-queue budget per frame lane; 288 GB of HBM make this cheap.  16 GB hold the queues of a whole batch of eight 1080p / 4 spp frames (7.4 M hits x
     // 2.1 KB) in ONE chunk: no hit-count read-back, half the launches (1.76-1.80 -> 1.68-1.72 ms per frame against 8 GB; profiles/r03_experiments.txt)
     size_t budgetBytes = (size_t)16 << 30;
-    TraceTune tune{32, 16, 0, 2, 0, 0, 0, 2, 0, 1, 0};   // chunk 0 = run length chosen in the kernel from the queue size
+    TraceTune tune{32, 16, 0, 2, 0, 0, 0, 2, 0, 1, 0, 768};   // chunk 0 = run length chosen in the kernel from the queue size
     // allocations
     size_t slotsCap = 0;      // per-frame arrays sized for this many pixel slots
     size_t chunkBytes = 0;    // bytes of the per-chunk arena
@@ -1643,8 +1645,8 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
     rt_stage_begin(ctx, ST_TRACE_PRIMARY, st);
     PrimarySrc ps;
     ps.fr = dFrame; ps.cand = wb.cand; ps.count = &wb.counts[0]; ps.outT = wb.primT; ps.outTri = wb.primTri;
-    TraceTune tuneP = tune;   // primary rays: one run = one 8x8 pixel block; their cost varies strongly across the screen, so short runs
-    if (tuneP.chunk == 0) tuneP.chunk = 64;   // balance the tail (stage alone 0.50 / 0.62 / 0.86 ms with runs of 64 / 128 / 256)
+    TraceTune tuneP = tune;   // primary rays: their cost varies strongly across the screen, so shorter runs than the queue launches (128 - 256, see k_trace)
+    tuneP.chunkMax = 256;
     if (const char *e = getenv("RT_CHUNK_PRIMARY")) tuneP.chunk = atoi(e);
     launch_trace<PrimarySrc, false>(st, w->cus, gridPctPrimary, treeDepth, dFrame, host.sc, ps, &wb.heads[0], w->acc + 2, w->acc + 8, tuneP, S ? S + 0 : nullptr);
     rt_stage_end(ctx, ST_TRACE_PRIMARY, 1, st);
@@ -1757,14 +1759,14 @@ void rt_wave_trace_closest_indexed(hipStream_t st, int cus, int treeDepth, const
                                    const uint32_t *count, const float4 *o, const float4 *d, float *outT, int *outTri, uint32_t *heads) {
     IndexedSrc q;
     q.idx = idx; q.count = count; q.o = o; q.d = d; q.outT = outT; q.outTri = outTri; q.n = 0;
-    TraceTune tune{32, 16, 0, 2, 0, 0, 0, 2, 0, 1, 0};
+    TraceTune tune{32, 16, 0, 2, 0, 0, 0, 2, 0, 1, 0, 768};
     launch_trace<IndexedSrc, false>(st, cus, 100, treeDepth, dFrame, hostScene, q, heads, nullptr, nullptr, tune, nullptr);
 }
 void rt_wave_trace_closest_compact(hipStream_t st, int cus, int treeDepth, const DevFrame *dFrame, const DevScene &hostScene, const float4 *o, const float4 *d,
                                    const uint32_t *dst, const uint32_t *count, const uint32_t *flags, uint32_t cap, float *outT, int *outTri, uint32_t *heads) {
     CompactSrc q;
     q.o = o; q.d = d; q.dst = dst; q.count = count; q.flags = flags; q.cap = cap; q.outT = outT; q.outTri = outTri; q.n = 0;
-    TraceTune tune{32, 16, 0, 2, 0, 0, 0, 2, 0, 1, 0};
+    TraceTune tune{32, 16, 0, 2, 0, 0, 0, 2, 0, 1, 0, 768};
     launch_trace<CompactSrc, false>(st, cus, 100, treeDepth, dFrame, hostScene, q, heads, nullptr, nullptr, tune, nullptr);
 }
 size_t rt_wave_head_words() { return kHeadWords; }

@@ -1,0 +1,18 @@
+#!/bin/bash
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/${1:-r04sw3}; mkdir -p $OUT; cd $R
+run() { echo -n "[$*] " | tee -a $OUT/sweep.log; for i in 1 2 3; do env "$@" timeout -k 10 120 python3 tools/wall_batch.py 1 8 2>&1 | tail -1 | awk '{printf "%s ", $5}' | tee -a $OUT/sweep.log; done; echo | tee -a $OUT/sweep.log; }
+run A=0
+run RT_GRID_PCT=60
+run RT_GRID_PCT=67
+run A=0
+run RT_GRID_PCT=85
+run RT_GRID_PCT=100
+run A=0
+run RT_REFILL_MIN=24
+run RT_REFILL_MIN=40
+run RT_MIN_SEARCH=8
+run RT_MIN_SEARCH=24
+run A=0
+run RT_CHUNK=384
+run RT_CHUNK=1024
+run A=0
