@@ -116,6 +116,8 @@ def parse_args(argv=None):
     ap.add_argument("--gi-bounces", type=int, default=1, help="EXTENSION: diffuse bounces of the analytic / hybrid GI path (configs[2]: 4)")
     ap.add_argument("--parity-window", default="64x32", help="WxH of the oracle window around the frame centre that the last timed frame is compared "
                     "with after the timed run (full history chain from frame 0, all host threads); 0 = skip the parity block")
+    ap.add_argument("--no-run-b", action="store_true", help="skip the short side measurement of BASELINE configs[2] as written (\"run B\": bunny + glass + mirror, "
+                    "16 spp, 4 bounces -- the labelled hybrid EXTENSION) that the default line carries in `extension_run_b`")
     ap.add_argument("--n1-ms", type=float, default=None, help="N > 1: ms_per_step of the same workload on one GPU -> config.multi_gpu.efficiency_vs_n1")
     return ap.parse_args(argv)
 
@@ -707,6 +709,27 @@ def main():
                                "frame_seconds_estimate": {"threads_1": rays / args.steps / (r1 / t1), "threads_all": rays / args.steps / (rn / tn)},
                                "note": "the CPU traces every reference ray; the GPU pipeline skips duplicates (config.ray_accounting), so compare "
                                        "frame times (frame_seconds_estimate vs ms_per_step), or value_traversed, not the two Mray/s figures"}
+    # ---- BASELINE configs[2] AS WRITTEN ("bunny + glass + mirror materials ..., 16 spp, 4 bounces": run B).  The reference cannot express it (rt.frag:84-163: its BVH
+    # mode has no analytic objects or materials, its analytic mode no mesh, both one bounce), so it exists here only as the labelled hybrid EXTENSION, with
+    # parity against this repository's own oracle.  The default line carries a short measurement of it so that the driver's record shows both runs; configs[2] / [3] are
+    # still REPORTED as run A (`--spp 16`).  A child process of this command (the same bench.py with --hybrid); its failure does not fail the line.
+    if rank == 0 and world == 1 and headline and not args.no_run_b:
+        cmd = [sys.executable, str(ROOT / "bench.py"), "--hybrid", "--spp", "16", "--gi-bounces", "4", "--steps", "4", "--warmup", "2", "--cpu-seconds", "0",
+               "--no-default-camera", "--no-frame-by-frame", "--no-diagnostics", "--no-run-b", "--parity-window", "32x16"]
+        try:
+            r_b = subprocess.run(cmd, cwd=str(ROOT), capture_output=True, text=True, timeout=240)
+            lines_b = [ln for ln in r_b.stdout.splitlines() if ln.startswith("{")]
+            if r_b.returncode == 0 and len(lines_b) == 1:
+                b_ = json.loads(lines_b[0])
+                out["extension_run_b"] = {"what": "EXTENSION, not in the reference: BASELINE configs[2] as written (run B) through the staged hybrid pipeline; parity vs this repository's own oracle",
+                                          "workload": b_["config"]["workload"], "metric": b_["metric"], "ms_per_step": b_["ms_per_step"], "value": b_["value"], "unit": b_["unit"],
+                                          "steps": b_["steps"], "stage_ms_per_frame": b_.get("stage_ms_per_frame"), "hbm": b_["config"].get("hbm"),
+                                          "parity": {k: b_["parity"][k] for k in ("vs", "window", "frames_chained", "rmse", "bit_diff", "ok")} if b_.get("parity") else None,
+                                          "command": " ".join(cmd[1:])}
+            else:
+                out["extension_run_b"] = {"error": "exit code %d" % r_b.returncode, "stderr_tail": r_b.stderr[-300:]}
+        except Exception as e:   # noqa: BLE001
+            out["extension_run_b"] = {"error": repr(e)[:300]}
     if multi:
         import faulthandler
         faulthandler.cancel_dump_traceback_later()
