@@ -271,12 +271,15 @@ struct PrimarySrc {   // ray i = primary ray of candidate i
     }
     RT_DEV void store_closest(uint32_t i, float t, int tri) const { outT[i] = t; outTri[i] = tri; }
     RT_DEV void store_any(uint32_t, bool) const {}
+    RT_DEV bool dense(uint32_t, uint32_t) const { return false; }
+    RT_DEV float probe_take(uint32_t, V3 &, V3 &, uint32_t &) const { return -1.0f; }
 };
 struct QueueSrc {     // slot-major queue: ray r -> (slot = r / n, j = r % n) at [slot*stride + j], n = live entries
     const float4 *o, *d;
     const float *tm;             // per-slot tMax / liveness
     const uint32_t *liveCount;   // device counter the live entry count derives from
     uint32_t c0, cap, stride, slots;
+    uint32_t denseSlots;         // the first `denseSlots` slots hold a ray for (nearly) every entry (AO slots, the bounce queue): see dense() below
     float *outT;
     int *outTri;
     uint8_t *outOcc;
@@ -300,6 +303,17 @@ struct QueueSrc {     // slot-major queue: ray r -> (slot = r / n, j = r % n) at
     }
     RT_DEV void store_closest(uint32_t a, float t, int tri) const { outT[a] = t; outTri[a] = tri; }
     RT_DEV void store_any(uint32_t a, bool occ) const { outOcc[a] = occ ? 1 : 0; }
+    // Dense slots (round 4): where (nearly) every entry is a ray the liveness probe is a wasted round trip -- the i-th idle lane takes the i-th entry
+    // left and reads liveness word and record together; an entry that is dead after all (AO radius 0, GI switched off) just leaves its lane idle.
+    RT_DEV bool dense(uint32_t r0, uint32_t r1) const { return r1 > r0 && (r1 - 1u) / nLive < denseSlots; }
+    RT_DEV float probe_take(uint32_t r, V3 &ro, V3 &rd, uint32_t &token) const {
+        const uint32_t a = addr(r);
+        const float t = tm[a];
+        const float4 oo = o[a], dd = d[a];
+        token = a;
+        ro = f4xyz(oo); rd = f4xyz(dd);
+        return t;
+    }
 };
 
 // Two any-hit queues traced by ONE persistent launch (direct shadows + AO, then the shadows at the bounce hits): a second
@@ -328,6 +342,8 @@ struct DualQueueSrc {
         if (token & 0x80000000u) b.outOcc[token & 0x7fffffffu] = occ ? 1 : 0;
         else a.outOcc[token] = occ ? 1 : 0;
     }
+    RT_DEV bool dense(uint32_t r0, uint32_t r1) const { return r1 <= na && a.dense(r0, r1); }
+    RT_DEV float probe_take(uint32_t r, V3 &ro, V3 &rd, uint32_t &token) const { return a.probe_take(r, ro, rd, token); }
 };
 
 // A dense list of queue addresses (rt_hybrid.hip): ray r is the record at idx[r]; every listed record is a ray.
@@ -350,6 +366,8 @@ struct IndexedSrc {
     }
     RT_DEV void store_closest(uint32_t a, float t, int tri) const { outT[a] = t; outTri[a] = tri; }
     RT_DEV void store_any(uint32_t, bool) const {}
+    RT_DEV bool dense(uint32_t, uint32_t) const { return false; }
+    RT_DEV float probe_take(uint32_t, V3 &, V3 &, uint32_t &) const { return -1.0f; }
 };
 
 // A dense array of ray records (rt_hybrid.hip, round 4): ray r is the record o[r] / d[r]; its answer goes to outT / outTri at dst[r] (the asking
@@ -375,6 +393,8 @@ struct CompactSrc {
     }
     RT_DEV void store_closest(uint32_t a, float t, int tri) const { outT[a] = t; outTri[a] = tri; }
     RT_DEV void store_any(uint32_t, bool) const {}
+    RT_DEV bool dense(uint32_t, uint32_t) const { return false; }
+    RT_DEV float probe_take(uint32_t, V3 &, V3 &, uint32_t &) const { return -1.0f; }
 };
 
 // hipcc sinks loads into the branches that first use them (e.g. a triangle's v0 behind the determinant test), which turns
@@ -461,7 +481,7 @@ RT_DEV uint32_t quad_distinct(uint32_t key) {
 constexpr uint32_t kShards = 64, kShardStride = 32;   // cursor shards per trace launch, uint32 words between them (128 B)
 constexpr uint32_t kHeadWords = kShards * kShardStride;
 
-struct TraceTune { int refillMin; int minSearch; int chunk; int leafb; int skipTraversal; int quadRefill; int coop; int leafbClosest; int nearFirst; int reverse; int guided; int chunkMax; };   // skipTraversal: diagnostic (RT_DEBUG_SKIP_TRAVERSAL)
+struct TraceTune { int refillMin; int minSearch; int chunk; int leafb; int skipTraversal; int quadRefill; int coop; int leafbClosest; int nearFirst; int reverse; int guided; int chunkMax; int denseTake; };   // skipTraversal: diagnostic (RT_DEBUG_SKIP_TRAVERSAL)
 
 template <bool ANY> struct StackOf { typedef StackEntry type; };          // closest: {deferred child, its entry distance}
 template <> struct StackOf<true> { typedef uint32_t type; };              // any-hit: the pop-time cull never fires (tMax is constant)
@@ -619,9 +639,40 @@ __global__ __launch_bounds__(256, (!STATS && !ANY) ? 5 : (NEAR ? 6 : (ANY && !ST
             // (coalesced), the live slots go to the idle lanes in order and dead slots cost nothing further.  (Before, a refill
             // handed out `idle lanes` consecutive slots dead or alive and went round again: with 55 % of the shadow queue's slots
             // dead, three rounds -- each a full scheduler iteration -- to fill half a wave.)
+            // a lane starts on the ray it was given (record in ro / rd, any-hit limit tMax)
+            auto start_ray = [&](float tMax, uint32_t token) {
+                rayId = token;
+                traced++;
+                rdInv = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+                tBest = ANY ? tMax : inf;
+                triBest = -1;
+                sp = 0;
+                leaf = 0;
+                ref = ANY ? sc.rootRef4 : sc.rootRefW;
+                if (ANY && ref < 0) { leaf = ref; ref = RT_NO_CHILD; }   // single-leaf tree
+                float tmin;
+                bool in = sc.hasBVH && !tune.skipTraversal && slab(ro, rdInv, ld3(sc.rootMin), ld3(sc.rootMax), tmin) && !(tmin > tBest);
+                if (in) active = true;
+                else if (ANY) src.store_any(token, false);
+                else src.store_closest(token, inf, -1);
+            };
             unsigned long long idleLeft = idleMask;
             while (idleLeft != 0ull && runNext < runEnd) {
                 const uint32_t window = min(64u, runEnd - runNext);
+                if (tune.denseTake && src.dense(runNext, runNext + window)) {
+                    // dense slots: no probe -- the i-th idle lane reads the i-th entry left, liveness word and record in ONE round trip
+                    const uint32_t nIdleL = (uint32_t)__popcll(idleLeft);
+                    const uint32_t nTake = min(window, nIdleL);
+                    const uint32_t rank = (uint32_t)__popcll(idleLeft & ((1ull << lane) - 1ull));
+                    if (((idleLeft >> lane) & 1ull) && rank < nTake) {
+                        uint32_t token;
+                        const float tMax = src.probe_take(runNext + rank, ro, rd, token);
+                        if (!(tMax < 0.0f)) start_ray(tMax, token);
+                    }
+                    runNext += nTake;
+                    idleLeft = whole_quads(__ballot(!active));
+                    continue;
+                }
                 float t = -1.0f;
                 typename Src::Payload pl{};
                 if (lane < window) t = src.probe(runNext + lane, pl);
@@ -636,20 +687,7 @@ __global__ __launch_bounds__(256, (!STATS && !ANY) ? 5 : (NEAR ? 6 : (ANY && !ST
                 if (takes) {
                     uint32_t token;
                     src.take(runNext + e, mine, ro, rd, token);
-                    rayId = token;
-                    traced++;
-                    rdInv = mk3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
-                    tBest = ANY ? tMax : inf;
-                    triBest = -1;
-                    sp = 0;
-                    leaf = 0;
-                    ref = ANY ? sc.rootRef4 : sc.rootRefW;
-                    if (ANY && ref < 0) { leaf = ref; ref = RT_NO_CHILD; }   // single-leaf tree
-                    float tmin;
-                    bool in = sc.hasBVH && !tune.skipTraversal && slab(ro, rdInv, ld3(sc.rootMin), ld3(sc.rootMax), tmin) && !(tmin > tBest);
-                    if (in) active = true;
-                    else if (ANY) src.store_any(token, false);
-                    else src.store_closest(token, inf, -1);
+                    start_ray(tMax, token);
                 }
                 // all live slots taken: the window is used up; else everything before the first live slot left over
                 runNext += nLiveW <= nIdleL ? window : nth_set(liveMask, nTake);
@@ -1414,7 +1452,7 @@ struct RtWave {
     // ray-queue budget per frame lane; 288 GB of HBM make this cheap.  16 GB hold the queues of a whole batch of eight 1080p / 4 spp frames (7.4 M hits x
     // 2.1 KB) in ONE chunk: no hit-count read-back, half the launches (1.76-1.80 -> 1.68-1.72 ms per frame against 8 GB; profiles/r03_experiments.txt)
     size_t budgetBytes = (size_t)16 << 30;
-    TraceTune tune{32, 16, 0, 2, 0, 0, 0, 2, 0, 1, 0, 768};   // chunk 0 = run length chosen in the kernel from the queue size
+    TraceTune tune{32, 16, 0, 2, 0, 0, 0, 2, 0, 1, 0, 768, 1};   // chunk 0 = run length chosen in the kernel from the queue size
     // allocations
     size_t slotsCap = 0;      // per-frame arrays sized for this many pixel slots
     size_t chunkBytes = 0;    // bytes of the per-chunk arena
@@ -1451,7 +1489,8 @@ RtWave *rt_wave_create(int cus, RtArenaPool *pool, int lane) {
     if (const char *e = getenv("RT_BIN_GI")) w->binGi = atoi(e) != 0;
     if (const char *e = getenv("RT_NEAR_FIRST")) w->tune.nearFirst = atoi(e);
     if (const char *e = getenv("RT_REVERSE")) w->tune.reverse = atoi(e);
-    if (const char *e = getenv("RT_GUIDED")) w->tune.guided = atoi(e);     // 0: runs of one length, as in rounds 1-3   // 0: any-hit queues dealt from their beginning, as in rounds 1-3
+    if (const char *e = getenv("RT_GUIDED")) w->tune.guided = atoi(e);
+    if (const char *e = getenv("RT_DENSE_TAKE")) w->tune.denseTake = atoi(e);   // 0: every refill probes liveness first, as in rounds 2-3     // 0: runs of one length, as in rounds 1-3   // 0: any-hit queues dealt from their beginning, as in rounds 1-3
     if (const char *e = getenv("RT_PACKET_AO")) w->packetAO = atoi(e) != 0;
     (void)hipEventCreateWithFlags(&w->hopEv, hipEventDisableTiming);
     if (const char *e = getenv("RT_CU_SPLIT")) {
@@ -1706,11 +1745,12 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
         QueueSrc q1;
         q1.o = wb.shO + skip; q1.d = wb.shD + skip; q1.tm = wb.shT + skip; q1.liveCount = &wb.counts[1]; q1.c0 = c0; q1.cap = wb.CH; q1.stride = wb.CH;
         q1.slots = (uint32_t)(S1 - (pkAO ? A : 0));
+        q1.denseSlots = pkAO ? 0u : (uint32_t)A;
         q1.outT = nullptr; q1.outTri = nullptr; q1.outOcc = wb.occ1 + skip;
         if (u.enableGI == 1) {
             // bounce rays first, then ONE any-hit launch over both shadow queues
             QueueSrc qg;
-            qg.o = wb.giO; qg.d = wb.giD; qg.tm = wb.giL; qg.liveCount = &wb.counts[1]; qg.c0 = c0; qg.cap = wb.CH; qg.stride = wb.CH; qg.slots = (uint32_t)SPP;
+            qg.o = wb.giO; qg.d = wb.giD; qg.tm = wb.giL; qg.liveCount = &wb.counts[1]; qg.c0 = c0; qg.cap = wb.CH; qg.stride = wb.CH; qg.slots = (uint32_t)SPP; qg.denseSlots = (uint32_t)SPP;
             qg.outT = wb.giT; qg.outTri = wb.giTri; qg.outOcc = nullptr;
             rt_stage_begin(ctx, ST_TRACE_GI, st);
             launch_trace<QueueSrc, false>(st, w->cus, gridPct, treeDepth, dFrame, host.sc, qg, &wb.heads[(size_t)(1 + c * 4 + 1) * kHeadWords], w->acc + 4, w->acc + 10, tune, S ? S + 32 : nullptr);
@@ -1725,7 +1765,7 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
             DualQueueSrc qq;
             qq.a = q1;
             qq.b.o = wb.sh2O; qq.b.d = wb.sh2D; qq.b.tm = wb.sh2T; qq.b.liveCount = &wb.counts[64 + c]; qq.b.c0 = 0; qq.b.cap = wb.CH * (uint32_t)SPP;
-            qq.b.stride = wb.CH * (uint32_t)SPP; qq.b.slots = 6u;
+            qq.b.stride = wb.CH * (uint32_t)SPP; qq.b.slots = 6u; qq.b.denseSlots = 0u;
             qq.b.outT = nullptr; qq.b.outTri = nullptr; qq.b.outOcc = wb.occ2;
             rt_stage_begin(ctx, ST_TRACE_SHADOW, st);
             launch_trace<DualQueueSrc, true>(st, w->cus, gridPct, treeDepth, dFrame, host.sc, qq, &wb.heads[(size_t)(1 + c * 4 + 0) * kHeadWords], w->acc + 3, w->acc + 9, tune, S ? S + 16 : nullptr);
@@ -1759,14 +1799,14 @@ void rt_wave_trace_closest_indexed(hipStream_t st, int cus, int treeDepth, const
                                    const uint32_t *count, const float4 *o, const float4 *d, float *outT, int *outTri, uint32_t *heads) {
     IndexedSrc q;
     q.idx = idx; q.count = count; q.o = o; q.d = d; q.outT = outT; q.outTri = outTri; q.n = 0;
-    TraceTune tune{32, 16, 0, 2, 0, 0, 0, 2, 0, 1, 0, 768};
+    TraceTune tune{32, 16, 0, 2, 0, 0, 0, 2, 0, 1, 0, 768, 1};
     launch_trace<IndexedSrc, false>(st, cus, 100, treeDepth, dFrame, hostScene, q, heads, nullptr, nullptr, tune, nullptr);
 }
 void rt_wave_trace_closest_compact(hipStream_t st, int cus, int treeDepth, const DevFrame *dFrame, const DevScene &hostScene, const float4 *o, const float4 *d,
                                    const uint32_t *dst, const uint32_t *count, const uint32_t *flags, uint32_t cap, float *outT, int *outTri, uint32_t *heads) {
     CompactSrc q;
     q.o = o; q.d = d; q.dst = dst; q.count = count; q.flags = flags; q.cap = cap; q.outT = outT; q.outTri = outTri; q.n = 0;
-    TraceTune tune{32, 16, 0, 2, 0, 0, 0, 2, 0, 1, 0, 768};
+    TraceTune tune{32, 16, 0, 2, 0, 0, 0, 2, 0, 1, 0, 768, 1};
     launch_trace<CompactSrc, false>(st, cus, 100, treeDepth, dFrame, hostScene, q, heads, nullptr, nullptr, tune, nullptr);
 }
 size_t rt_wave_head_words() { return kHeadWords; }
