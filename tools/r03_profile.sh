@@ -10,8 +10,8 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 has() { [[ " $STEPS " == *" $1 "* ]]; }
-BENCH="python3 $R/bench.py --steps 40 --warmup 8 --cpu-seconds 0 --no-default-camera --no-frame-by-frame --no-diagnostics"
-BENCH1M="python3 $R/bench.py --scene 1m --steps 8 --warmup 8 --cpu-seconds 0 --no-default-camera --no-frame-by-frame --no-diagnostics"
+BENCH="python3 $R/bench.py --steps 40 --warmup 8 --cpu-seconds 0 --no-default-camera --no-frame-by-frame --no-diagnostics --no-run-b"
+BENCH1M="python3 $R/bench.py --scene 1m --steps 8 --warmup 8 --cpu-seconds 0 --no-default-camera --no-frame-by-frame --no-diagnostics --no-run-b"
 pmc() {   # pmc <outdir> <counters...> -- <program...>
   local d=$1; shift; local c=(); while [[ "$1" != "--" ]]; do c+=("$1"); shift; done; shift
   mkdir -p $(dirname $d); timeout -k 10 400 rocprofv3 --pmc "${c[@]}" --output-format csv -d $d -- "$@" > $d.log 2>&1 || { echo "pmc pass $d failed"; tail -3 $d.log; }
