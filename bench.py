@@ -316,7 +316,11 @@ def main():
         ren.synchronize()
         torch.cuda.synchronize()
         ren.traced_rays(reset=True)
-        if timed_stage:
+        # Stage events (two hipEventRecord per stage and batch) stay out of the single-GPU timed region: each is host work between a batch's hit-count read-back and
+        # its next launches, 1.5 % of the driver's 20-step run (1.692 -> 1.666 ms per step, three runs each).  The overlapped spans come from an untimed pass below;
+        # a tile-parallel run keeps them in (its gather diagnostics are measured in the timed region, and N > 1 lines are not the headline).
+        events_in_timed_region = timed_stage and multi
+        if events_in_timed_region:
             ren.enable_stage_timing(True)
             if isinstance(gatherer, FrameGatherer):
                 gatherer.timed = True
@@ -332,7 +336,7 @@ def main():
         if multi:
             dist.barrier()
         dt = time.perf_counter() - t0
-        stages = ren.stage_times() if timed_stage else None
+        stages = ren.stage_times() if events_in_timed_region else None
         traced = ren.traced_rays()
         info = ren.scene_info()
         batched_hash = color_hash(ren) if check else None
@@ -350,6 +354,17 @@ def main():
                 final_targets = [gatherer.frame_halfs()] if rank == 0 else None
             else:
                 final_targets = ren.read_all()
+        stage_frames, stage_traced = steps, traced
+        if timed_stage and not events_in_timed_region:
+            # the same batches once more, untimed, with the stage events on: spans of the stages while launch sets overlap (the targets have been read above)
+            n_extra = min(2 * B, warmup + steps)
+            ren.traced_rays(reset=True)
+            ren.enable_stage_timing(True)
+            for f_ in range(0, n_extra, B):
+                ren.render_frames(frames_u[f_:min(f_ + B, n_extra)])
+            ren.synchronize()
+            stages = ren.stage_times()
+            stage_frames, stage_traced = n_extra, ren.traced_rays()
         assembled_same = None
         if args.rehearse_one_gpu and gatherer is not None and world > 1:
             # rank 0: the frame the ranks' tiles were assembled into == the same frames rendered by one context that owns every tile
@@ -398,7 +413,7 @@ def main():
             dist.all_reduce(tr, op=dist.ReduceOp.SUM)
         frames_all = max(int(tr[1].item()) // world, 1)
         traced_per_frame = int(tr[0].item()) // frames_all if traced.frames else 0
-        return {"seconds": float(tt.item()), "seconds_own": dt_own, "memory": mem, "comm": comm, "gather_py": gather_py, "final_targets": final_targets, "frames_u": frames_u,
+        return {"seconds": float(tt.item()), "seconds_own": dt_own, "memory": mem, "stage_frames": stage_frames, "stage_traced": stage_traced, "comm": comm, "gather_py": gather_py, "final_targets": final_targets, "frames_u": frames_u,
                 "counters": total, "local_counters": cnt, "stages": stages,
                 "traced_per_frame": traced_per_frame, "traced": traced, "scene_info": info, "counted_frames": steps,
                 "batched_hash": batched_hash, "fbf_hash": fbf_hash, "fbf_ms": fbf_ms, "same": bool(same.item()) if check else None,
@@ -461,7 +476,7 @@ def main():
     roofline = None
     st = res["stages"]
     if st and st["stages"]:
-        src = serial if serial else {"stages": st["stages"], "traced": res["traced"], "frames": args.steps}
+        src = serial if serial else {"stages": st["stages"], "traced": res["stage_traced"], "frames": res["stage_frames"]}
         name, dom = max(src["stages"].items(), key=lambda kv: kv[1]["ms"])
         launches = max(int(dom["launches"]), 1)
         avg_ms = dom["ms"] / launches                  # HIP events around each launch of this kernel, on the stream it runs on
@@ -544,8 +559,8 @@ def main():
                     "cache_resident": bool(info.bytesNodes2 + info.bytesNodes4 + info.bytesPairs < 32 * 2**20),
                     "reference_layout": ref_layout, "l1_gather": l1,
                     "avg_launch_ms_source": ("HIP events around the launches of an untimed pass with ONE launch set in flight (RT_LANES=1), same batching as "
-                                             "the timed run; every launch traced rays" if serial else "HIP events, timed region (launch sets of several "
-                                             "batches overlap: spans include time shared with other kernels)"),
+                                             "the timed run; every launch traced rays" if serial else "HIP events, untimed pass after the timed region (N > 1: the timed region); "
+                                             "launch sets of several batches overlap: spans include time shared with other kernels"),
                     "note": "hbm frac = compulsory bytes of the launch / its duration / 8 TB/s.  With the BVH resident in L2 / Infinity Cache "
                             "(cache_resident) HBM is not what bounds the kernel -- a low frac is expected; the binding bound is the L1 access "
                             "rate (l1_gather), see DESIGN.md 4.3"}
@@ -597,8 +612,9 @@ def main():
                             "what": "hipMemGetInfo on this rank's device right after the timed run (this context + the runtime's own allocations); "
                                     "the ray-queue arenas are shared by the frame lanes (RT_ARENAS) and sized for one batch of frames each"}
     if st:
-        out["stage_ms_per_frame"] = {k: v["ms"] / args.steps for k, v in st["stages"].items()}
-        out["stage_ms_note"] = "HIP-event spans in the timed region; consecutive batches overlap on 3-4 streams, so spans add up to more than ms_per_step"
+        out["stage_ms_per_frame"] = {k: v["ms"] / res["stage_frames"] for k, v in st["stages"].items()}
+        out["stage_ms_note"] = ("HIP-event spans of an untimed pass over the same batches (N > 1: of the timed region); consecutive batches overlap on four streams, "
+                                "so spans add up to more than ms_per_step")
     if serial:
         out["stage_ms_per_frame_one_launch_set_in_flight"] = {k: v["ms"] / serial["frames"] for k, v in serial["stages"].items()}
 
