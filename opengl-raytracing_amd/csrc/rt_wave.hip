@@ -1499,6 +1499,13 @@ RtWave *rt_wave_create(int cus, RtArenaPool *pool, int lane) {
         for (int i = 0; i < 8; ++i) { uint32_t m = 0; for (int b = 0; b < 32; ++b) if (((i * 32 + b) & 7) < k) m |= 1u << b; mask[i] = m; }
         if (hipExtStreamCreateWithCUMask(&w->shadeStream, 8, mask) != hipSuccess) w->shadeStream = nullptr;
     }   // quad-cooperative node fetch of the closest-hit launches (measured option)
+    // EXPERIMENT RT_SHADE_PRIORITY=p: the shading kernels on a second stream of queue priority p (-1 high, 1 low; no CU mask), the traversal launches on the lane's own
+    else if (const char *e = getenv("RT_SHADE_PRIORITY")) {
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        const int p = std::max(greatest, std::min(least, atoi(e)));
+        if (hipStreamCreateWithPriority(&w->shadeStream, hipStreamNonBlocking, p) != hipSuccess) w->shadeStream = nullptr;
+    }
     return w;
 }
 void rt_wave_destroy(RtWave *w) {
