@@ -25,6 +25,7 @@ using namespace rtd;
 static thread_local std::string g_createError;
 
 #define RT_MAX_LANES 8
+constexpr size_t kQNodesAbove = (size_t)4 << 20;   // bytes of 112-byte any-hit nodes beyond which the quantised nodes are built and walked
 constexpr int kDefaultArenas = 2;   // ray-queue arenas shared by the frame lanes (rt_wave.hpp RtArenaPool; measured in profiles/r04_experiments.txt)
 struct StageEvent { int stage; hipEvent_t a, b; };
 
@@ -42,6 +43,7 @@ struct RtContext {
     std::string err;
     // scene
     float4 *dWNodes = nullptr, *dW4 = nullptr, *dTris = nullptr, *dWNodesW = nullptr, *dPairs = nullptr;
+    float4 *dQ4 = nullptr, *dLeafBox = nullptr;   // RT_QNODES: quantised any-hit nodes + the leaves' exact boxes
     int rootRefW = 0;
     void *dHistAll[RT_MAX_LANES] = {};      // tile-parallel + moving camera: every rank's COLOR0 block of the frame a lane rendered
     bool histExchanged[RT_MAX_LANES] = {};
@@ -215,6 +217,8 @@ DevScene make_dev_scene(const RtContext *c) {
     DevScene s;
     s.wnodes = c->dWNodes;
     s.w4 = c->dW4;
+    s.q4 = c->dQ4;
+    s.leafBox = c->dLeafBox;
     s.wnodesW = c->dWNodesW;
     s.pairs = c->dPairs;
     s.rootRefW = c->rootRefW;
@@ -391,6 +395,8 @@ void rt_destroy(RtContext *c) {
     for (int i = 0; i < RT_MAX_LANES; ++i) if (c->lanes[i]) (void)hipStreamDestroy(c->lanes[i]);   // c->stream is lanes[0]
     if (c->dWNodes) (void)hipFree(c->dWNodes);
     if (c->dW4) (void)hipFree(c->dW4);
+    if (c->dQ4) (void)hipFree(c->dQ4);
+    if (c->dLeafBox) (void)hipFree(c->dLeafBox);
     if (c->dWNodesW) (void)hipFree(c->dWNodesW);
     if (c->dPairs) (void)hipFree(c->dPairs);
     if (c->dTris) (void)hipFree(c->dTris);
@@ -410,10 +416,12 @@ int rt_upload_bvh(RtContext *c, const float *nodes12, int nNodes, const float *t
     HIP_TRY(c, sync_all(c));
     if (c->dWNodes) (void)hipFree(c->dWNodes);
     if (c->dW4) (void)hipFree(c->dW4);
+    if (c->dQ4) (void)hipFree(c->dQ4);
+    if (c->dLeafBox) (void)hipFree(c->dLeafBox);
     if (c->dWNodesW) (void)hipFree(c->dWNodesW);
     if (c->dPairs) (void)hipFree(c->dPairs);
     if (c->dTris) (void)hipFree(c->dTris);
-    c->dWNodes = c->dW4 = c->dTris = c->dWNodesW = c->dPairs = nullptr;
+    c->dWNodes = c->dW4 = c->dTris = c->dWNodesW = c->dPairs = c->dQ4 = c->dLeafBox = nullptr;
     c->nNodes = c->nTris = c->nInner = 0;
     c->treeDepth = 0;
     c->nWide4 = c->nPairs = 0;
@@ -697,7 +705,81 @@ int rt_upload_bvh(RtContext *c, const float *nodes12, int nNodes, const float *t
         }
         anyStack = std::max(need[0], 1);
     }
+    // Round 4: the any-hit tree once more with QUANTISED child boxes -- 64 bytes per 4-wide node instead of 112, four gather loads per
+    // visit instead of seven.  Only the reference's LEAVES need their exact boxes (an any-hit answer is the OR over the leaves that pass their own box test);
+    // an inner box may be any box that contains them, and the slab arithmetic is monotonic in the box, so a decoded box that is checked HERE, in the very
+    // float expression the kernel decodes with (fmaf(q, 2^e, origin)), to contain the child's box passes whenever the child's does.  A leaf child passes
+    // the quantised test first and its exact box -- kept in `leafBox`, indexed by the leaf's first pair record -- in the leaf phase.
+    // Built (and walked, rt_wave.hip launch_trace) when the 112-byte nodes outgrow one XCD's 4 MB L2 (kQNodesAbove): the decode costs 48 VALU operations per
+    // visit and a wave per SIMD, which a cache-resident tree does not earn back -- any-hit launch per frame, exact / quantised nodes, one launch set in flight:
+    // 20 k triangles 0.57 / 0.63-0.66 ms, 82 k (bench mesh, 0.6 MB of nodes) 0.66 / 0.74, 328 k (2.4 MB) 0.81 / 0.83-0.84, 1 M (9.8 MB) 15.9 / 13.6
+    // (profiles/r04_experiments.txt 19).  RT_QNODES=0 / 2 forces either.
+    //   piece 0: origin.xyz (float), biased exponents ex | ey << 8 | ez << 16       piece 1: lo.x lo.y lo.z hi.x, one byte per child
+    //   piece 2: hi.y hi.z - -                                                       piece 3: the four child references of the 112-byte node
+    std::vector<uint32_t> q4;
+    std::vector<float> leafBox;
+    const int qmode = getenv("RT_QNODES") ? atoi(getenv("RT_QNODES")) : -1;
+    if (rootRef4 == 0 && (qmode > 0 || (qmode < 0 && (w4.size() / 32) * 112 > kQNodesAbove))) {
+        const size_t n4 = w4.size() / 32;
+        q4.assign(n4 * 16, 0u);
+        bool okQ = true;
+        for (size_t nn = 0; nn < n4 && okQ; ++nn) {
+            const float *o = &w4[nn * 32];
+            int refs[4];
+            std::memcpy(refs, o + 24, 16);
+            uint32_t *q = &q4[nn * 16];
+            float org[3], scale[3];
+            uint32_t exps = 0;
+            for (int a = 0; a < 3; ++a) {
+                float lo = INFINITY, hi = -INFINITY;
+                for (int i = 0; i < 4; ++i) if (refs[i] != RT_NO_CHILD) { lo = std::min(lo, o[4 * a + i]); hi = std::max(hi, o[12 + 4 * a + i]); }
+                if (!(lo <= hi)) { lo = hi = 0.0f; }
+                int eb = 1;
+                const double ext = ((double)hi - (double)lo) / 255.0;
+                if (ext > 0.0) { int e2; (void)std::frexp(ext, &e2); eb = std::max(1, e2 - 1 + 127); }
+                while (eb <= 254 && std::fmaf(255.0f, std::ldexp(1.0f, eb - 127), lo) < hi) ++eb;
+                if (eb > 254) { okQ = false; break; }
+                org[a] = lo; scale[a] = std::ldexp(1.0f, eb - 127);
+                exps |= (uint32_t)eb << (8 * a);
+                std::memcpy(&q[a], &lo, 4);
+            }
+            if (!okQ) break;
+            q[3] = exps;
+            for (int i = 0; i < 4; ++i) {
+                q[12 + i] = (uint32_t)refs[i];
+                if (refs[i] == RT_NO_CHILD) continue;
+                for (int a = 0; a < 3; ++a) {
+                    const float lo = o[4 * a + i], hi = o[12 + 4 * a + i];
+                    int ql = (int)std::floor(((double)lo - (double)org[a]) / (double)scale[a]);
+                    ql = std::max(0, std::min(255, ql));
+                    while (ql > 0 && std::fmaf((float)ql, scale[a], org[a]) > lo) --ql;
+                    int qh = (int)std::ceil(((double)hi - (double)org[a]) / (double)scale[a]);
+                    qh = std::max(0, std::min(255, qh));
+                    while (qh < 255 && std::fmaf((float)qh, scale[a], org[a]) < hi) ++qh;
+                    if (std::fmaf((float)ql, scale[a], org[a]) > lo || std::fmaf((float)qh, scale[a], org[a]) < hi) okQ = false;
+                    const int wl = 4 + a, wh = a == 0 ? 7 : 7 + a;      // words: lo.x lo.y lo.z hi.x | hi.y hi.z
+                    q[wl] |= (uint32_t)ql << (8 * i);
+                    q[wh] |= (uint32_t)qh << (8 * i);
+                }
+            }
+        }
+        if (okQ) {
+            leafBox.assign((pairs.size() / 20) * 8, 0.0f);
+            for (int i = 0; i < nNodes; ++i) if (nd[(size_t)i].count > 0) {
+                const size_t first = (size_t)(-pairRefOf[(size_t)i] - 1) >> 3;
+                const float *b = nodes12 + (size_t)i * 12;
+                const float box[8] = {b[0], b[1], b[2], b[4], b[5], b[6], 0.0f, 0.0f};
+                std::memcpy(&leafBox[first * 8], box, sizeof box);
+            }
+        } else q4.clear();
+    }
     if (depth > 32) return fail(c, RT_ERR_UNSUPPORTED, "rt_upload_bvh: tree depth %d exceeds the 32-entry traversal stack", depth);
+    if (!q4.empty()) {
+        HIP_TRY(c, hipMalloc(&c->dQ4, q4.size() * 4));
+        HIP_TRY(c, hipMemcpy(c->dQ4, q4.data(), q4.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMalloc(&c->dLeafBox, leafBox.size() * 4));
+        HIP_TRY(c, hipMemcpy(c->dLeafBox, leafBox.data(), leafBox.size() * 4, hipMemcpyHostToDevice));
+    }
     HIP_TRY(c, hipMalloc(&c->dWNodes, wn.size() * sizeof(float)));
     HIP_TRY(c, hipMalloc(&c->dW4, w4.size() * sizeof(float)));
     HIP_TRY(c, hipMemcpy(c->dW4, w4.data(), w4.size() * sizeof(float), hipMemcpyHostToDevice));

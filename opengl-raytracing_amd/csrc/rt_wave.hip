@@ -481,7 +481,7 @@ RT_DEV uint32_t quad_distinct(uint32_t key) {
 constexpr uint32_t kShards = 64, kShardStride = 32;   // cursor shards per trace launch, uint32 words between them (128 B)
 constexpr uint32_t kHeadWords = kShards * kShardStride;
 
-struct TraceTune { int refillMin; int minSearch; int chunk; int leafb; int skipTraversal; int quadRefill; int coop; int leafbClosest; int nearFirst; int reverse; int guided; int chunkMax; int denseTake; };   // skipTraversal: diagnostic (RT_DEBUG_SKIP_TRAVERSAL)
+struct TraceTune { int refillMin; int minSearch; int chunk; int leafb; int skipTraversal; int quadRefill; int coop; int leafbClosest; int nearFirst; int reverse; int guided; int chunkMax; int denseTake; int qnodes; };   // skipTraversal: diagnostic (RT_DEBUG_SKIP_TRAVERSAL)
 
 template <bool ANY> struct StackOf { typedef StackEntry type; };          // closest: {deferred child, its entry distance}
 template <> struct StackOf<true> { typedef uint32_t type; };              // any-hit: the pop-time cull never fires (tMax is constant)
@@ -495,10 +495,10 @@ extern __shared__ __align__(16) unsigned char rt_dyn_lds[];
 #ifndef RT_ANYHIT_WAVES
 #define RT_ANYHIT_WAVES 7   // any-hit launches: 72 VGPRs, seven waves per SIMD (with the exact stack size of rt_upload_bvh seven workgroups fit a CU's LDS)
 #endif
-template <class Src, bool ANY, int LEAFB, bool STATS = false, bool COOP = false, bool NEAR = false>
-__global__ __launch_bounds__(256, (!STATS && !ANY) ? 5 : (NEAR ? 6 : (ANY && !STATS && LEAFB == 2 ? RT_ANYHIT_WAVES : 1))) void k_trace(const DevFrame *__restrict__ fr, const float4 *__restrict__ wnodes, const float4 *__restrict__ tris, Src src,
+template <class Src, bool ANY, int LEAFB, bool STATS = false, bool COOP = false, bool NEAR = false, int QN = 0>
+__global__ __launch_bounds__(256, (!STATS && !ANY) ? 5 : ((NEAR || QN == 2) ? 6 : (ANY && !STATS && LEAFB == 2 ? RT_ANYHIT_WAVES : 1))) void k_trace(const DevFrame *__restrict__ fr, const float4 *__restrict__ wnodes, const float4 *__restrict__ tris, Src src,
                                                 uint32_t *head, unsigned long long *tally, unsigned long long *gatherLoads, TraceTune tune,
-                                                int stackEntries, unsigned long long *stats = nullptr) {
+                                                int stackEntries, unsigned long long *stats = nullptr, const float4 *__restrict__ leafBox = nullptr) {
     // STATS (diagnostic build only, RT_TRACE_STATS=1): [0] inner-node visits [1] leaf visits [2] triangle tests [3] inner-phase wave
     // iterations [4] active lanes summed over them [5] leaf-phase wave iterations [6] lanes with a leaf summed [7] refill rounds
     unsigned long long st_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // [14] / [15]: the same with wave-wide merging (distinct records per wave step)   // [8] cycles in inner steps [9] in leaf phases [10] in refills [11] wave lifetime
@@ -724,22 +724,47 @@ __global__ __launch_bounds__(256, (!STATS && !ANY) ? 5 : (NEAR ? 6 : (ANY && !ST
             }
             if (searching) {
                 if (STATS) { st_[0]++; const uint32_t dk = quad_distinct((uint32_t)ref), dw = wave_distinct((uint32_t)ref); if (lane == (uint32_t)(__ffsll((long long)sm) - 1)) { st_[12] += dk * (ANY ? 7u : 4u); st_[14] += dw * (ANY ? 7u : 4u); } }
-                gathers += ANY ? 7u : 4u;
+                gathers += ANY ? (QN ? 4u : 7u) : 4u;
                 if constexpr (ANY) {
+                    int r0, r1, r2, r3;
+                    float t0, t1, t2, t3;
+                    bool h0, h1, h2, h3;
+                    if constexpr (QN) {
+                        // RT_QNODES: 64-byte node, child boxes as bytes on the node's own grid (rt_upload_bvh): box = fmaf(byte, 2^e, origin) per component,
+                        // checked at upload to contain the child's box; then the slab test of the exact kernel on the decoded floats
+                        const v4f *ndv = reinterpret_cast<const v4f *>(nodes + (size_t)ref * 4);
+                        v4f p0 = ndv[0], p1 = ndv[1], p2 = ndv[2], p3 = ndv[3];
+                        pin(p0); pin(p1); pin(p2); pin(p3);
+                        r0 = (int)f2u(p3.x); r1 = (int)f2u(p3.y); r2 = (int)f2u(p3.z); r3 = (int)f2u(p3.w);
+                        const uint32_t ex = f2u(p0.w);
+                        const float sx = u2f((ex & 0xffu) << 23), sy = u2f(((ex >> 8) & 0xffu) << 23), sz = u2f(((ex >> 16) & 0xffu) << 23);
+                        const uint32_t lx = f2u(p1.x), ly = f2u(p1.y), lz = f2u(p1.z), hx = f2u(p1.w), hy = f2u(p2.x), hz = f2u(p2.y);
+                        auto box = [&](int k, float &t) {
+                            const V3 lo = mk3(__builtin_fmaf((float)((lx >> (8 * k)) & 0xffu), sx, p0.x), __builtin_fmaf((float)((ly >> (8 * k)) & 0xffu), sy, p0.y),
+                                              __builtin_fmaf((float)((lz >> (8 * k)) & 0xffu), sz, p0.z));
+                            const V3 hi = mk3(__builtin_fmaf((float)((hx >> (8 * k)) & 0xffu), sx, p0.x), __builtin_fmaf((float)((hy >> (8 * k)) & 0xffu), sy, p0.y),
+                                              __builtin_fmaf((float)((hz >> (8 * k)) & 0xffu), sz, p0.z));
+                            return slab(ro, rdInv, lo, hi, t) && t <= tBest;
+                        };
+                        h0 = box(0, t0) && r0 != RT_NO_CHILD;
+                        h1 = box(1, t1) && r1 != RT_NO_CHILD;
+                        h2 = box(2, t2) && r2 != RT_NO_CHILD;
+                        h3 = box(3, t3) && r3 != RT_NO_CHILD;
+                    } else {
                     // 4-wide node: up to four grandchild boxes per 128-byte record, order irrelevant for any-hit
                     const float4 *nd = nodes + (size_t)ref * 8;
                     // component-wise: [min.x x4][min.y x4][min.z x4][max.x x4][max.y x4][max.z x4][ref x4] = 7 loads, 8th piece unused
                     const v4f *ndv = reinterpret_cast<const v4f *>(nd);
                     v4f q0 = ndv[0], q1 = ndv[1], q2 = ndv[2], q3 = ndv[3], q4 = ndv[4], q5 = ndv[5], q6 = ndv[6];
                     pin(q0); pin(q1); pin(q2); pin(q3); pin(q4); pin(q5); pin(q6);
-                    int r0 = (int)f2u(q6.x), r1 = (int)f2u(q6.y), r2 = (int)f2u(q6.z), r3 = (int)f2u(q6.w);
-                    float t0, t1, t2, t3;
-                    bool h0 = slab(ro, rdInv, mk3(q0.x, q1.x, q2.x), mk3(q3.x, q4.x, q5.x), t0) && t0 <= tBest;
-                    bool h1 = slab(ro, rdInv, mk3(q0.y, q1.y, q2.y), mk3(q3.y, q4.y, q5.y), t1) && t1 <= tBest;
+                    r0 = (int)f2u(q6.x); r1 = (int)f2u(q6.y); r2 = (int)f2u(q6.z); r3 = (int)f2u(q6.w);
+                    h0 = slab(ro, rdInv, mk3(q0.x, q1.x, q2.x), mk3(q3.x, q4.x, q5.x), t0) && t0 <= tBest;
+                    h1 = slab(ro, rdInv, mk3(q0.y, q1.y, q2.y), mk3(q3.y, q4.y, q5.y), t1) && t1 <= tBest;
                     // absent children carry NaN boxes: with v_min/v_max NaN semantics their slab test is false, so all
                     // loads are issued up front and the four tests are branch-free (no dependent "is there a child" round trip)
-                    bool h2 = slab(ro, rdInv, mk3(q0.z, q1.z, q2.z), mk3(q3.z, q4.z, q5.z), t2) && t2 <= tBest;
-                    bool h3 = slab(ro, rdInv, mk3(q0.w, q1.w, q2.w), mk3(q3.w, q4.w, q5.w), t3) && t3 <= tBest;
+                    h2 = slab(ro, rdInv, mk3(q0.z, q1.z, q2.z), mk3(q3.z, q4.z, q5.z), t2) && t2 <= tBest;
+                    h3 = slab(ro, rdInv, mk3(q0.w, q1.w, q2.w), mk3(q3.w, q4.w, q5.w), t3) && t3 <= tBest;
+                    }
                     // Any-hit order is free, so leaves are postponed: the first leaf met goes to `leaf`, the lane goes on with an
                     // inner child (or pops one), and leaves are tested in the leaf phase when (nearly) every lane holds one --
                     // both phases run with more lanes busy than when a lane stops at its first leaf.
@@ -803,6 +828,21 @@ __global__ __launch_bounds__(256, (!STATS && !ANY) ? 5 : (NEAR ? 6 : (ANY && !ST
             int v = -leafNow - 1;
             int first = v >> 3, count = (v & 7) + 1;   // first: pair record, count: triangles
             bool done = false;
+            // RT_QNODES: the leaf's exact box (the test the 112-byte node makes in the parent) -- fetched together with the first triangle group, tested after it
+            bool boxOK = true;
+            v4f lb0 = {0, 0, 0, 0}, lb1 = lb0;
+            if constexpr (QN) {
+                const v4f *lb = reinterpret_cast<const v4f *>(leafBox) + (size_t)first * 2;
+                lb0 = lb[0]; lb1 = lb[1];
+                gathers += 2u;
+            }
+            auto gate = [&]() {
+                if constexpr (QN) {
+                    pin(lb0); pin(lb1);
+                    float tb;
+                    boxOK = slab(ro, rdInv, mk3(lb0.x, lb0.y, lb0.z), mk3(lb0.w, lb1.x, lb1.y), tb) && tb <= tBest;
+                }
+            };
             // Two triangles of a leaf share one 80-byte record (5 gather loads instead of 6).  Records of a leaf are contiguous:
             // fetch LEAFB/2 of them at a time so that the gather round trips of one group overlap (the array is padded, so no
             // bounds branch); test in leaf order.
@@ -821,6 +861,7 @@ __global__ __launch_bounds__(256, (!STATS && !ANY) ? 5 : (NEAR ? 6 : (ANY && !ST
                 for (int k = 0; k < NPG; ++k) { rec[k][0] = tv[k * 5 + 0]; rec[k][1] = tv[k * 5 + 1]; rec[k][2] = tv[k * 5 + 2]; rec[k][3] = tv[k * 5 + 3]; rec[k][4] = tv[k * 5 + 4]; }
 #pragma unroll
                 for (int k = 0; k < NPG; ++k) { pin(rec[k][0]); pin(rec[k][1]); pin(rec[k][2]); pin(rec[k][3]); pin(rec[k][4]); }
+                if (QN && i == 0) gate();
 #pragma unroll
                 for (int k = 0; k < 2 * NPG; ++k) {
                     const v4f &r0 = rec[k >> 1][0], &r1 = rec[k >> 1][1], &r2 = rec[k >> 1][2], &r3 = rec[k >> 1][3], &r4 = rec[k >> 1][4];
@@ -829,7 +870,7 @@ __global__ __launch_bounds__(256, (!STATS && !ANY) ? 5 : (NEAR ? 6 : (ANY && !ST
                     const V3 e2 = (k & 1) ? mk3(r3.w, r4.x, r4.y) : mk3(r1.z, r1.w, r2.x);
                     float tt;
                     if (STATS && !done) st_[2]++;
-                    if (!done && tri_hit(ro, rd, v0, e1, e2, eps, tBest, tt)) {
+                    if (!done && boxOK && tri_hit(ro, rd, v0, e1, e2, eps, tBest, tt)) {
                         if (ANY) done = true;
                         else { tBest = tt; triBest = (int)f2u(r4.z) + (k & 1); }
                     }
@@ -837,19 +878,20 @@ __global__ __launch_bounds__(256, (!STATS && !ANY) ? 5 : (NEAR ? 6 : (ANY && !ST
             };
             int i = 0;
             if constexpr (LEAFB >= 4) for (; i + 4 <= count && !done; i += 4) group(std::integral_constant<int, 2>{}, i);
-            for (; i + 2 <= count && !done; i += 2) group(std::integral_constant<int, 1>{}, i);
+            for (; i + 2 <= count && !done && boxOK; i += 2) group(std::integral_constant<int, 1>{}, i);
             // ... then the odd last triangle of the leaf: its record holds ONE triangle, whose nine floats (and, for closest-hit rays, its
             // index, repeated in the otherwise unused tenth float) sit in the first three 16-byte pieces: 3 gather loads instead of 5
             // (every leaf of the bench mesh has 5 triangles: 13 loads per leaf visit instead of 15).
-            if ((count & 1) && !done) {
+            if ((count & 1) && !done && boxOK) {
                 const float4 *t = sc.tris + (size_t)(first + (count >> 1)) * 5;
                 gathers += 3u;
                 if (STATS) { const unsigned long long am = __ballot(1); const uint32_t dk = quad_distinct((uint32_t)(first + (count >> 1))), dw = wave_distinct((uint32_t)(first + (count >> 1))); if (lane == (uint32_t)(__ffsll((long long)am) - 1)) { st_[13] += dk * 3u; st_[15] += dw * 3u; } st_[2]++; }
                 const v4f *tv = reinterpret_cast<const v4f *>(t);
                 v4f r0 = tv[0], r1 = tv[1], r2 = tv[2];
                 pin(r0); pin(r1); pin(r2);
+                if (QN && count == 1) gate();
                 float tt;
-                if (tri_hit(ro, rd, mk3(r0.x, r0.y, r0.z), mk3(r0.w, r1.x, r1.y), mk3(r1.z, r1.w, r2.x), eps, tBest, tt)) {
+                if (boxOK && tri_hit(ro, rd, mk3(r0.x, r0.y, r0.z), mk3(r0.w, r1.x, r1.y), mk3(r1.z, r1.w, r2.x), eps, tBest, tt)) {
                     if (ANY) done = true;
                     else { tBest = tt; triBest = (int)f2u(r2.y); }
                 }
@@ -1377,7 +1419,8 @@ void launch_trace(hipStream_t st, int cus, int gridPct, int depth, const DevFram
     // registers: asked from the runtime per (kernel, stack size), the persistent grid is exactly what fits.
     const int stack = std::max(4, ANY ? (hs.anyStack > 0 ? hs.anyStack : 3 * ((depth + 1) / 2)) : depth);
     const size_t ldsBytes = (size_t)256 * stack * (ANY ? 4 : 8);
-    const float4 *nodes = ANY ? hs.w4 : hs.wnodesW;
+    const bool qn = ANY && tune.qnodes != 0 && hs.q4 != nullptr && !stats;   // -1: whenever rt_upload_bvh built the quantised nodes (trees beyond the L2)
+    const float4 *nodes = ANY ? (qn ? hs.q4 : hs.w4) : hs.wnodesW;
     auto go = [&](auto kernel) {
         // the runtime's answer per (device, kernel, LDS bytes): a process may hold contexts on devices of different shapes
         thread_local std::map<std::tuple<int, const void *, size_t>, int> occ;
@@ -1389,12 +1432,14 @@ void launch_trace(hipStream_t st, int cus, int gridPct, int depth, const DevFram
             perCU = std::min(perCU, 8);
         }
         const unsigned blocks = (unsigned)std::max(8, cus * perCU * gridPct / 100);
-        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), ldsBytes, st, fr, nodes, hs.pairs, src, head, tally, gatherLoads, tune, stack, stats);
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), ldsBytes, st, fr, nodes, hs.pairs, src, head, tally, gatherLoads, tune, stack, stats, hs.leafBox);
     };
     const int leafb = ANY ? tune.leafb : tune.leafbClosest;
     if (stats) { if (leafb >= 4) go(k_trace<Src, ANY, 4, true>); else go(k_trace<Src, ANY, 2, true>); }
     else if (!ANY && tune.coop) go(k_trace<Src, ANY, 2, false, !ANY>);
     else if (ANY && tune.nearFirst) go(k_trace<Src, ANY, 2, false, false, ANY>);
+    else if (qn && tune.qnodes == 1) go(k_trace<Src, ANY, 2, false, false, false, ANY ? 1 : 0>);   // seven waves per SIMD, 44 B of scratch: slower (measured)
+    else if (qn) go(k_trace<Src, ANY, 2, false, false, false, ANY ? 2 : 0>);
     else       { if (leafb >= 4) go(k_trace<Src, ANY, 4, false>); else go(k_trace<Src, ANY, 2, false>); }
 }
 
@@ -1452,7 +1497,7 @@ struct RtWave {
     // ray-queue budget per frame lane; 288 GB of HBM make this cheap.  16 GB hold the queues of a whole batch of eight 1080p / 4 spp frames (7.4 M hits x
     // 2.1 KB) in ONE chunk: no hit-count read-back, half the launches (1.76-1.80 -> 1.68-1.72 ms per frame against 8 GB; profiles/r03_experiments.txt)
     size_t budgetBytes = (size_t)16 << 30;
-    TraceTune tune{32, 16, 0, 2, 0, 0, 0, 2, 0, 1, 0, 768, 1};   // chunk 0 = run length chosen in the kernel from the queue size
+    TraceTune tune{32, 16, 0, 2, 0, 0, 0, 2, 0, 1, 0, 768, 1, -1};   // chunk 0 = run length chosen in the kernel from the queue size
     // allocations
     size_t slotsCap = 0;      // per-frame arrays sized for this many pixel slots
     size_t chunkBytes = 0;    // bytes of the per-chunk arena
@@ -1492,6 +1537,7 @@ RtWave *rt_wave_create(int cus, RtArenaPool *pool, int lane) {
     if (const char *e = getenv("RT_GUIDED")) w->tune.guided = atoi(e);
     if (const char *e = getenv("RT_DENSE_TAKE")) w->tune.denseTake = atoi(e);   // 0: every refill probes liveness first, as in rounds 2-3     // 0: runs of one length, as in rounds 1-3   // 0: any-hit queues dealt from their beginning, as in rounds 1-3
     if (const char *e = getenv("RT_PACKET_AO")) w->packetAO = atoi(e) != 0;
+    if (const char *e = getenv("RT_QNODES")) w->tune.qnodes = atoi(e);        // 0: never; 1 / 2: always (seven / six waves per SIMD); default: when rt_upload_bvh built them
     (void)hipEventCreateWithFlags(&w->hopEv, hipEventDisableTiming);
     if (const char *e = getenv("RT_CU_SPLIT")) {
         const int k = std::max(1, std::min(7, atoi(e)));
@@ -1806,14 +1852,14 @@ void rt_wave_trace_closest_indexed(hipStream_t st, int cus, int treeDepth, const
                                    const uint32_t *count, const float4 *o, const float4 *d, float *outT, int *outTri, uint32_t *heads) {
     IndexedSrc q;
     q.idx = idx; q.count = count; q.o = o; q.d = d; q.outT = outT; q.outTri = outTri; q.n = 0;
-    TraceTune tune{32, 16, 0, 2, 0, 0, 0, 2, 0, 1, 0, 768, 1};
+    TraceTune tune{32, 16, 0, 2, 0, 0, 0, 2, 0, 1, 0, 768, 1, -1};
     launch_trace<IndexedSrc, false>(st, cus, 100, treeDepth, dFrame, hostScene, q, heads, nullptr, nullptr, tune, nullptr);
 }
 void rt_wave_trace_closest_compact(hipStream_t st, int cus, int treeDepth, const DevFrame *dFrame, const DevScene &hostScene, const float4 *o, const float4 *d,
                                    const uint32_t *dst, const uint32_t *count, const uint32_t *flags, uint32_t cap, float *outT, int *outTri, uint32_t *heads) {
     CompactSrc q;
     q.o = o; q.d = d; q.dst = dst; q.count = count; q.flags = flags; q.cap = cap; q.outT = outT; q.outTri = outTri; q.n = 0;
-    TraceTune tune{32, 16, 0, 2, 0, 0, 0, 2, 0, 1, 0, 768, 1};
+    TraceTune tune{32, 16, 0, 2, 0, 0, 0, 2, 0, 1, 0, 768, 1, -1};
     launch_trace<CompactSrc, false>(st, cus, 100, treeDepth, dFrame, hostScene, q, heads, nullptr, nullptr, tune, nullptr);
 }
 size_t rt_wave_head_words() { return kHeadWords; }

@@ -191,6 +191,39 @@ def test_anyhit_sah_tree_option(orc, monkeypatch, mesh):
         assert mesh == "one_leaf" or tr.shadow > 0
 
 
+@pytest.mark.parametrize("qn,mesh,sah", [(2, "one_leaf", 0), (2, "tiny", 0), (2, "deep", 0), (1, "deep", 0), (2, "deep", 1)])
+def test_quantised_anyhit_nodes(orc, monkeypatch, qn, mesh, sah):
+    """RT_QNODES (round 4; the default for any-hit trees beyond 4 MB of nodes, forced here on small meshes): the any-hit launches walk 64-byte nodes
+    whose child boxes are bytes on the node's own grid -- supersets of the exact boxes, checked at upload in the kernel's own decode expression --
+    and test a leaf's exact box in the leaf phase.  Answers depend only on which reference leaves pass their own box test, so frames stay
+    bit-identical to the oracle: single-leaf mesh (no quantised tree is built), one-level tree, depth-12 tree, the seven-wave build of the
+    kernel, and the quantised form of the SAH any-hit tree."""
+    monkeypatch.setenv("RT_QNODES", str(qn))           # read by rt_upload_bvh and by the renderer's launch sets
+    if sah:
+        monkeypatch.setenv("RT_ANYHIT_TREE", "sah")
+    W, H = 96, 64
+    if mesh == "one_leaf":
+        tris9 = np.array([[-1, 0, -1, 1, 0, -1, 0, 1.5, -1.2], [-1, 0, 1, 1, 0, 1, 0, 1.5, 0.5]], np.float32) + np.float32(0.25)
+        nodes, tris = rt.build_bvh(tris9)
+    else:
+        nodes, tris = scenes.bunny_bvh(0 if mesh == "tiny" else 4)
+    faces = scenes.tiny_env(8)
+    p = rt.default_render_params()
+    p.sppPerFrame = 2
+    cam = scenes.camera("closeup", aspect=W / H)
+    with rt.Renderer(pipeline=rt.RT_PIPELINE_WAVEFRONT) as r:
+        r.upload_bvh(nodes, tris)
+        r.upload_env(faces)
+        r.resize(W, H)
+        prev = None
+        for f in range(2):
+            u = rt.frame_uniforms(p, cam, W, H, f, True, nodes.shape[0], tris.shape[0])
+            r.render_frame(u)
+            want, _ = orc.render(u, nodes, tris, faces, prev)
+            _assert_targets_equal(r.read_all(), want, orc, f"RT_QNODES={qn} sah={sah} {mesh} frame={f}")
+            prev = want[0]
+
+
 @pytest.fixture(scope="module")
 def ren_wave():
     r = rt.Renderer(pipeline=rt.RT_PIPELINE_WAVEFRONT)
