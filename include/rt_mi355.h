@@ -284,7 +284,9 @@ int rt_reset_counters(RtContext *ctx);
 
 /* What rt_upload_bvh made of the scene: the device arrays of DESIGN.md 3 (64-byte two-child records for closest-hit rays, 128-byte
  * four-child records for any-hit rays, 80-byte triangle-pair records, the reference's 48-byte triangles for normals) and their
- * sizes -- the bytes a traversal launch has to bring in at most once (bench.py's HBM roofline). */
+ * sizes -- the bytes a traversal launch has to bring in at most once (bench.py's HBM roofline).  When the any-hit tree is larger than
+ * 4 MB the any-hit launches walk its quantised form instead: bytesNodes4 is then 64 bytes per four-child record + 32
+ * bytes of exact box per leaf. */
 typedef struct RtSceneInfo {
     int32_t nNodes, nTris, nInner, treeDepth, nWide4, nPairs;
     uint64_t bytesNodes2, bytesNodes4, bytesPairs, bytesTris;

@@ -51,6 +51,7 @@ struct RtContext {
     int envSize = 0;
     int nNodes = 0, nTris = 0, nInner = 0, rootRef = 0, rootRef4 = 0, treeDepth = 0;
     size_t nWide4 = 0, nPairs = 0;   // records in dW4 / dPairs
+    size_t nLeafBoxes = 0;           // leaves with an exact box in dLeafBox (quantised any-hit nodes)
     int anyStack = 0;                // stack entries of the any-hit walk (0: from the binary depth)
     float rootMin[3] = {0, 0, 0}, rootMax[3] = {0, 0, 0};
     // frame state
@@ -765,7 +766,9 @@ int rt_upload_bvh(RtContext *c, const float *nodes12, int nNodes, const float *t
         }
         if (okQ) {
             leafBox.assign((pairs.size() / 20) * 8, 0.0f);
+            c->nLeafBoxes = 0;
             for (int i = 0; i < nNodes; ++i) if (nd[(size_t)i].count > 0) {
+                ++c->nLeafBoxes;
                 const size_t first = (size_t)(-pairRefOf[(size_t)i] - 1) >> 3;
                 const float *b = nodes12 + (size_t)i * 12;
                 const float box[8] = {b[0], b[1], b[2], b[4], b[5], b[6], 0.0f, 0.0f};
@@ -1220,7 +1223,7 @@ int rt_get_scene_info(const RtContext *c, RtSceneInfo *out) {
     if (c->nNodes == 0) return RT_OK;
     out->nWide4 = (int32_t)c->nWide4; out->nPairs = (int32_t)c->nPairs;
     out->bytesNodes2 = (uint64_t)std::max(c->nInner, 1) * 64;
-    out->bytesNodes4 = (uint64_t)c->nWide4 * 128;
+    out->bytesNodes4 = c->dQ4 ? (uint64_t)c->nWide4 * 64 + (uint64_t)c->nLeafBoxes * 32 : (uint64_t)c->nWide4 * 128;   // the any-hit launches walk the quantised nodes when they exist
     out->bytesPairs = (uint64_t)c->nPairs * 80;
     out->bytesTris = (uint64_t)c->nTris * 48;
     return RT_OK;
