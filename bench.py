@@ -555,7 +555,9 @@ def main():
                     "traffic_frac_of_peak": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                     "avg_launch_ms": avg_ms, "launches": launches, "frames_per_launch": src["frames"] / launches,
                     "algorithmic_bytes_per_launch": bytes_per_launch, "attribution": attribution,
-                    "bvh_bytes": {"nodes_2wide": info.bytesNodes2, "nodes_4wide": info.bytesNodes4, "triangle_pairs": info.bytesPairs},
+                    "bvh_bytes": {"nodes_2wide": info.bytesNodes2, "nodes_4wide": info.bytesNodes4, "triangle_pairs": info.bytesPairs,
+                                  "nodes_4wide_form": ("quantised: 64 B per node + 32 B of exact box per leaf (any-hit trees beyond 4 MB, DESIGN.md 4.2)"
+                                                       if info.bytesNodes4 != info.nWide4 * 128 else "exact: 128 B per node (112 B read)")},
                     "cache_resident": bool(info.bytesNodes2 + info.bytesNodes4 + info.bytesPairs < 32 * 2**20),
                     "reference_layout": ref_layout, "l1_gather": l1,
                     "avg_launch_ms_source": ("HIP events around the launches of an untimed pass with ONE launch set in flight (RT_LANES=1), same batching as "
