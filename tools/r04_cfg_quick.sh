@@ -12,3 +12,4 @@ run head
 run spp16 --spp 16
 run 1m4 --scene 1m --spp 4
 run 4k16 --size 3840x2160 --spp 16
+run 1m64 --scene 1m --spp 64 --steps 8 --warmup 8
