@@ -1419,7 +1419,7 @@ void launch_trace(hipStream_t st, int cus, int gridPct, int depth, const DevFram
     // registers: asked from the runtime per (kernel, stack size), the persistent grid is exactly what fits.
     const int stack = std::max(4, ANY ? (hs.anyStack > 0 ? hs.anyStack : 3 * ((depth + 1) / 2)) : depth);
     const size_t ldsBytes = (size_t)256 * stack * (ANY ? 4 : 8);
-    const bool qn = ANY && tune.qnodes != 0 && hs.q4 != nullptr && !stats;   // -1: whenever rt_upload_bvh built the quantised nodes (trees beyond the L2)
+    const bool qn = ANY && tune.qnodes != 0 && hs.q4 != nullptr && !stats && !tune.nearFirst;   // (the diagnostic and near-first builds walk the exact nodes)   // -1: whenever rt_upload_bvh built the quantised nodes (trees beyond the L2)
     const float4 *nodes = ANY ? (qn ? hs.q4 : hs.w4) : hs.wnodesW;
     auto go = [&](auto kernel) {
         // the runtime's answer per (device, kernel, LDS bytes): a process may hold contexts on devices of different shapes

@@ -191,15 +191,20 @@ def test_anyhit_sah_tree_option(orc, monkeypatch, mesh):
         assert mesh == "one_leaf" or tr.shadow > 0
 
 
-@pytest.mark.parametrize("qn,mesh,sah", [(2, "one_leaf", 0), (2, "tiny", 0), (2, "deep", 0), (1, "deep", 0), (2, "deep", 1)])
+@pytest.mark.parametrize("qn,mesh,sah", [(2, "one_leaf", 0), (2, "tiny", 0), (2, "deep", 0), (1, "deep", 0), (2, "deep", 1), (2, "deep", "near"), (2, "deep", "leafb4")])
 def test_quantised_anyhit_nodes(orc, monkeypatch, qn, mesh, sah):
     """RT_QNODES (round 4; the default for any-hit trees beyond 4 MB of nodes, forced here on small meshes): the any-hit launches walk 64-byte nodes
     whose child boxes are bytes on the node's own grid -- supersets of the exact boxes, checked at upload in the kernel's own decode expression --
     and test a leaf's exact box in the leaf phase.  Answers depend only on which reference leaves pass their own box test, so frames stay
     bit-identical to the oracle: single-leaf mesh (no quantised tree is built), one-level tree, depth-12 tree, the seven-wave build of the
-    kernel, and the quantised form of the SAH any-hit tree."""
+    kernel, the quantised form of the SAH any-hit tree, and the form built while another kernel option is selected (round 4's stress matrix caught the
+    near-first build being handed the quantised array)."""
     monkeypatch.setenv("RT_QNODES", str(qn))           # read by rt_upload_bvh and by the renderer's launch sets
-    if sah:
+    if sah == "near":
+        monkeypatch.setenv("RT_NEAR_FIRST", "1")       # a kernel build that walks the exact nodes: must be handed those, not the quantised array
+    elif sah == "leafb4":
+        monkeypatch.setenv("RT_LEAFB", "4")            # the quantised build wins over the leaf-group option
+    elif sah:
         monkeypatch.setenv("RT_ANYHIT_TREE", "sah")
     W, H = 96, 64
     if mesh == "one_leaf":
