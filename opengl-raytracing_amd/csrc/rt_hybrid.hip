@@ -90,7 +90,8 @@ RT_DEV uint32_t wave_excl_scan(uint32_t v, uint32_t lane, uint32_t &total) {
 // (1080p, 16 spp, 4 bounces, all shading passes of a frame): 53.8 / 41.1 / 38.0 / 36.4 / 39.1 ms at 2 (no bound: 225 VGPRs) / 3 / 4 / 5 / 6 waves per SIMD.
 // Persistent: a fixed grid walks the tiles of 256 threads (first pass of a chunk: thread = (sample, slot) in order; later passes: the dense list of threads
 // whose speculation failed), so that the list length can stay on the device and every workgroup owns one staging area.
-__global__ __launch_bounds__(256, 5) void k_hybrid_shade(const DevFrame *__restrict__ fr, HybridBuf hb, int listed) {
+template <int WAVES>
+__global__ __launch_bounds__(256, WAVES) void k_hybrid_shade(const DevFrame *__restrict__ fr, HybridBuf hb, int listed) {
     __shared__ uint32_t sOpen[4], sRec[4], sLog[4], sBase[3], sOk;
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     __shared__ uint32_t sTile;
@@ -333,6 +334,7 @@ struct RtHybrid {
     void *arena = nullptr, *staging = nullptr;
     size_t arenaBytes = 0, stagingBytes = 0;
     int gridShade = 0;
+    int waves = 5;            // launch bound of the shading kernel (waves per SIMD), RT_HYBRID_WAVES
     uint32_t *cnt = nullptr, *heads = nullptr;
     uint32_t *hostCnt = nullptr;       // pinned
     unsigned long long passes = 0, launches = 0, redone = 0;
@@ -385,7 +387,10 @@ int rt_hybrid_render(RtHybrid *h, RtContext *ctx, hipStream_t st, const DevFrame
     }
     if (h->gridShade == 0) {
         int perCU = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_hybrid_shade, 256, 0) != hipSuccess || perCU < 1) perCU = 1;
+        h->waves = 5;
+        if (const char *e = getenv("RT_HYBRID_WAVES")) h->waves = atoi(e) == 4 ? 4 : atoi(e) == 6 ? 6 : atoi(e) == 3 ? 3 : 5;   // EXPERIMENT: register budget of the shading kernel
+        auto kfn = h->waves == 3 ? k_hybrid_shade<3> : h->waves == 4 ? k_hybrid_shade<4> : h->waves == 6 ? k_hybrid_shade<6> : k_hybrid_shade<5>;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kfn, 256, 0) != hipSuccess || perCU < 1) perCU = 1;
         h->gridShade = h->cus * std::min(perCU, 8);
     }
     // staging: one [qmax][256] area of origins and one of directions per resident workgroup
@@ -471,7 +476,8 @@ int rt_hybrid_render(RtHybrid *h, RtContext *ctx, hipStream_t st, const DevFrame
                 H_TRY(hipMemsetAsync(h->cnt + C_REC * kCnt, 0, sizeof(uint32_t), st));
                 H_TRY(hipMemsetAsync(h->cnt + C_TILE * kCnt, 0, sizeof(uint32_t), st));
                 rt_stage_begin(ctx, ST_COMBINE, st);
-                hipLaunchKernelGGL(k_hybrid_shade, dim3((unsigned)h->gridShade), dim3(256), 0, st, dFrame, hb, launched == 0 ? 0 : 1);
+                auto kfn = h->waves == 3 ? k_hybrid_shade<3> : h->waves == 4 ? k_hybrid_shade<4> : h->waves == 6 ? k_hybrid_shade<6> : k_hybrid_shade<5>;
+                hipLaunchKernelGGL(kfn, dim3((unsigned)h->gridShade), dim3(256), 0, st, dFrame, hb, launched == 0 ? 0 : 1);
                 hipLaunchKernelGGL(k_hybrid_note, dim3(1), dim3(1), 0, st, h->cnt);
                 rt_stage_end(ctx, ST_COMBINE, 2, st);
                 H_TRY(hipMemsetAsync(h->heads, 0, rt_wave_head_words() * sizeof(uint32_t), st));
