@@ -8,6 +8,7 @@ import sys
 from pathlib import Path
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -61,9 +62,11 @@ def _worker(rank, world, port, out_path):
     dist.destroy_process_group()
 
 
-def test_two_rank_tile_gather_equals_single_rank(tmp_path):
+@pytest.mark.parametrize("world", [2, 3])
+def test_two_rank_tile_gather_equals_single_rank(tmp_path, world):
+    """world 2 and 3: the 48x32 frame is six tiles -- three / two per rank, dealt round-robin."""
     out = tmp_path / "frames.npy"
-    mp.spawn(_worker, args=(2, _free_port(), str(out)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(out)), nprocs=world, join=True)
     frames = np.load(out)
     d = np.load(GOLDEN / "bvh_closeup_48x32.npz")
     for f in range(frames.shape[0]):
