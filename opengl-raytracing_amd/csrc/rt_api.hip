@@ -52,6 +52,7 @@ struct RtContext {
     int nNodes = 0, nTris = 0, nInner = 0, rootRef = 0, rootRef4 = 0, treeDepth = 0;
     size_t nWide4 = 0, nPairs = 0;   // records in dW4 / dPairs
     size_t nLeafBoxes = 0;           // leaves with an exact box in dLeafBox (quantised any-hit nodes)
+    uint32_t leafBoxMagic = 0;       // dLeafBox index of a leaf = (first pair record * magic) >> 32 (0: = first)
     int anyStack = 0;                // stack entries of the any-hit walk (0: from the binary depth)
     float rootMin[3] = {0, 0, 0}, rootMax[3] = {0, 0, 0};
     // frame state
@@ -220,6 +221,7 @@ DevScene make_dev_scene(const RtContext *c) {
     s.w4 = c->dW4;
     s.q4 = c->dQ4;
     s.leafBox = c->dLeafBox;
+    s.leafBoxMagic = c->leafBoxMagic;
     s.wnodesW = c->dWNodesW;
     s.pairs = c->dPairs;
     s.rootRefW = c->rootRefW;
@@ -765,15 +767,26 @@ int rt_upload_bvh(RtContext *c, const float *nodes12, int nNodes, const float *t
             }
         }
         if (okQ) {
-            leafBox.assign((pairs.size() / 20) * 8, 0.0f);
+            // A leaf's box sits at index first / R, R = the smallest number of pair records any leaf owns: consecutive leaves are at least R records apart,
+            // so the quotient is distinct per leaf, and the array is dense when the leaves are alike (a median-split tree: record counts differ by at most one).
+            // The kernel divides by multiplying with ceil(2^32 / R) (exact for first < 2^28, R <= 8); R = 1: the identity (magic 0).
+            int rmin = 8;
+            for (int i = 0; i < nNodes; ++i) if (nd[(size_t)i].count > 0) rmin = std::min(rmin, (nd[(size_t)i].count + 1) / 2);
+            if (getenv("RT_QNODES_SPARSE_BOXES")) rmin = 1;      // EXPERIMENT: one slot per pair record, as first built
+            c->leafBoxMagic = rmin <= 1 ? 0u : (uint32_t)((((uint64_t)1 << 32) + (uint64_t)rmin - 1) / (uint64_t)rmin);
+            leafBox.assign(((pairs.size() / 20) / (size_t)std::max(rmin, 1) + 1) * 8, 0.0f);
             c->nLeafBoxes = 0;
             for (int i = 0; i < nNodes; ++i) if (nd[(size_t)i].count > 0) {
                 ++c->nLeafBoxes;
                 const size_t first = (size_t)(-pairRefOf[(size_t)i] - 1) >> 3;
+                const size_t at = c->leafBoxMagic ? (size_t)(((uint64_t)first * c->leafBoxMagic) >> 32) : first;
                 const float *b = nodes12 + (size_t)i * 12;
                 const float box[8] = {b[0], b[1], b[2], b[4], b[5], b[6], 0.0f, 0.0f};
-                std::memcpy(&leafBox[first * 8], box, sizeof box);
+                if (at * 8 + 8 > leafBox.size() || leafBox[at * 8 + 6] != 0.0f) { okQ = false; break; }   // (cannot happen: distinct quotients)
+                std::memcpy(&leafBox[at * 8], box, sizeof box);
+                leafBox[at * 8 + 6] = 1.0f;                                                                  // slot taken
             }
+            if (!okQ) { q4.clear(); leafBox.clear(); }
         } else q4.clear();
     }
     if (depth > 32) return fail(c, RT_ERR_UNSUPPORTED, "rt_upload_bvh: tree depth %d exceeds the 32-entry traversal stack", depth);

@@ -30,7 +30,8 @@ struct DevScene {
     const float4 *wnodes;
     const float4 *w4;
     const float4 *q4;        // RT_QNODES: w4 with quantised child boxes, 4 x 16 bytes per node (null: not built), see rt_upload_bvh
-    const float4 *leafBox;   // RT_QNODES: 2 x float4 per pair record, filled at a leaf's first record: its exact box [lo.xyz hi.x][hi.yz - -]
+    const float4 *leafBox;   // RT_QNODES: 2 x float4 per leaf: its exact box [lo.xyz hi.x][hi.yz - -], at index (first pair record * leafBoxMagic) >> 32
+    uint32_t leafBoxMagic;   // ceil(2^32 / R), R = fewest pair records of a leaf (0: index = first pair record), see rt_upload_bvh
     const float4 *wnodesW;   // wnodes with pair-record leaf references (wavefront closest-hit kernels)
     const float4 *pairs;     // 5 x float4 per PAIR of triangles of a leaf: [v0 e1 e2][v0 e1 e2][index of the first][-], see rt_upload_bvh
     const float4 *tris;

@@ -832,7 +832,8 @@ __global__ __launch_bounds__(256, (!STATS && !ANY) ? 5 : ((NEAR || QN == 2) ? 6 
             bool boxOK = true;
             v4f lb0 = {0, 0, 0, 0}, lb1 = lb0;
             if constexpr (QN) {
-                const v4f *lb = reinterpret_cast<const v4f *>(leafBox) + (size_t)first * 2;
+                const uint32_t at = sc.leafBoxMagic ? __umulhi((uint32_t)first, sc.leafBoxMagic) : (uint32_t)first;
+                const v4f *lb = reinterpret_cast<const v4f *>(leafBox) + (size_t)at * 2;
                 lb0 = lb[0]; lb1 = lb[1];
                 gathers += 2u;
             }
