@@ -712,7 +712,7 @@ int rt_upload_bvh(RtContext *c, const float *nodes12, int nNodes, const float *t
     // visit instead of seven.  Only the reference's LEAVES need their exact boxes (an any-hit answer is the OR over the leaves that pass their own box test);
     // an inner box may be any box that contains them, and the slab arithmetic is monotonic in the box, so a decoded box that is checked HERE, in the very
     // float expression the kernel decodes with (fmaf(q, 2^e, origin)), to contain the child's box passes whenever the child's does.  A leaf child passes
-    // the quantised test first and its exact box -- kept in `leafBox`, indexed by the leaf's first pair record -- in the leaf phase.
+    // the quantised test first and its exact box -- kept in `leafBox`, indexed from the leaf's first pair record (below) -- in the leaf phase.
     // Built (and walked, rt_wave.hip launch_trace) when the 112-byte nodes outgrow one XCD's 4 MB L2 (kQNodesAbove): the decode costs 48 VALU operations per
     // visit and a wave per SIMD, which a cache-resident tree does not earn back -- any-hit launch per frame, exact / quantised nodes, one launch set in flight:
     // 20 k triangles 0.57 / 0.63-0.66 ms, 82 k (bench mesh, 0.6 MB of nodes) 0.66 / 0.74, 328 k (2.4 MB) 0.81 / 0.83-0.84, 1 M (9.8 MB) 15.9 / 13.6
