@@ -319,6 +319,30 @@ def test_1080p_whole_frames_against_the_oracle(orc):
     assert hit_pixels == hits
 
 
+def test_16spp_whole_frame_and_4k_band_against_the_oracle(orc):
+    """configs[2] run A (1920x1080, 16 spp) against the oracle over the WHOLE first frame, and configs[3] (3840x2160, 16 spp) over a band of 256 full-width
+    rows through the mesh -- every target, bit for bit (the full-size oracle checks were 64x32 / 32x16 windows; the rest of those frames
+    was covered by wavefront == megakernel only).  About 35 s of oracle time on the box's 16 host threads."""
+    nodes, tris = scenes.bunny_bvh(6)
+    faces = scenes.env_faces("Sky_01")
+    p = rt.default_render_params()
+    p.sppPerFrame = 16
+    cam = scenes.camera("closeup")
+    for (W, H), region in (((1920, 1080), None), ((3840, 2160), (0, 952, 3840, 1208))):
+        u = rt.frame_uniforms(p, cam, W, H, 0, True, nodes.shape[0], tris.shape[0])
+        with rt.Renderer() as r:
+            r.upload_bvh(nodes, tris)
+            r.upload_env(faces)
+            r.resize(W, H)
+            r.render_frame(u)
+            got = r.read_all()
+        want, cnt = orc.render(u, nodes, tris, faces, None, region=region, nthreads=16)
+        x0, y0, x1, y1 = region if region else (0, 0, W, H)
+        assert cnt.hitPixels > (x1 - x0) * (y1 - y0) // 4          # the band / frame really crosses the mesh
+        for g, w in zip(got, want):
+            assert np.array_equal(g[y0:y1, x0:x1], w[y0:y1, x0:x1]), (W, H)
+
+
 _BATCH_CHUNK_CODE = r'''
 import sys, numpy as np
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
