@@ -379,6 +379,37 @@ def test_batched_frames_with_chunked_queues_against_the_oracle(from_slots):
     assert "BATCH-CHUNKED-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+@pytest.mark.parametrize("cam_kind", ["default", "closeup"])
+def test_million_triangle_scene_whole_1080p_frames_against_the_oracle(orc, cam_kind):
+    """The 1 M-triangle scene of configs[4] at 1920x1080 / 4 spp, two accumulating frames as one batch, against the oracle over the whole frame and every
+    target -- the scene whose any-hit launches walk the QUANTISED nodes by default (any-hit tree beyond 4 MB), here at full size and not
+    only at 640x360; the same frames with the exact nodes forced (RT_QNODES=0 is read at upload) must be the same bits."""
+    v, f = rt.meshgen.million_triangle_scene()
+    nodes, tris = rt.build_bvh(rt.gather_triangles(v, f, np.eye(4, dtype=np.float32).reshape(-1)))
+    faces = scenes.env_faces("Sky_01")
+    W, H = 1920, 1080
+    p = rt.default_render_params()
+    p.sppPerFrame = 4
+    cam = scenes.camera(cam_kind)
+    us = [rt.frame_uniforms(p, cam, W, H, f_, True, nodes.shape[0], tris.shape[0]) for f_ in range(2)]
+    with rt.Renderer() as r:
+        r.upload_bvh(nodes, tris)
+        info = r.scene_info()
+        if "RT_QNODES" not in os.environ:
+            assert info.bytesNodes4 == info.nWide4 * 64 + 131072 * 32   # the quantised form is the one that is walked: 64 B per node + 32 B per leaf
+        r.upload_env(faces)
+        r.resize(W, H)
+        r.render_frames(us)
+        got = r.read_all()
+    prev = None
+    for u in us:
+        want, cnt = orc.render(u, nodes, tris, faces, prev, nthreads=16)
+        prev = want[0]
+    assert cnt.hitPixels > W * H // 16         # a tenth of the frame and more shows the spheres
+    for g, w_ in zip(got, want):
+        assert np.array_equal(g, w_)
+
+
 def test_config4_scene_spp_and_accumulation_together(orc):
     """BASELINE configs[4] with its three dimensions TOGETHER (they had only run one at a time): the 1 M-triangle multi-object
     scene, 64 spp, temporal accumulation over 32 frames -- at 192x120 (the oracle's cost is per pixel, sample and frame), rendered in batches of eight
