@@ -96,6 +96,32 @@ def test_hip_hybrid_frames_match_the_oracle(orc, bounces, spp, env, pipeline):
 
 
 @pytest.mark.gpu
+def test_staged_hybrid_run_b_settings_whole_frame_against_the_oracle(orc):
+    """Run B's own settings -- 1920x1080, 16 spp, four bounces, cube map -- on the staged pipeline, the whole frame of two accumulating frames against this
+    repository's oracle, every target bit for bit (the other oracle checks of the extension are 96x64 frames and the 32x16 window of bench.py's run-B line):
+    thousands of shading tiles per pass, every pass of the speculation / replay scheme, default capacity estimates."""
+    W, H = 1920, 1080
+    nodes, tris = _mesh_in_front_of_the_spheres()
+    faces = scenes.tiny_env(16)
+    p = rt.default_render_params()
+    p.sppPerFrame = 16
+    cam = scenes.camera("default", aspect=W / H)
+    with rt.Renderer(pipeline=rt.RT_PIPELINE_AUTO) as r:
+        r.upload_bvh(nodes, tris)
+        r.upload_env(faces)
+        r.resize(W, H)
+        r.set_extension(gi_bounces=4)
+        prev = None
+        for frame in range(2):
+            u = rt.frame_uniforms(p, cam, W, H, frame, rt.RT_SCENE_HYBRID, nodes.shape[0], tris.shape[0])
+            r.render_frame(u)
+            want, _ = orc.render(u, nodes, tris, faces, prev, gi_bounces=4, nthreads=16)
+            for g, w, name in zip(r.read_all(), want, ("color", "motion", "gpos", "gnrm")):
+                assert np.array_equal(g, w), (frame, name, orc.compare(g, w))
+            prev = want[0]
+
+
+@pytest.mark.gpu
 def test_hip_hybrid_with_empty_bvh_is_the_analytic_mode(orc):
     W, H = 128, 80
     faces = scenes.tiny_env(8)
