@@ -114,7 +114,7 @@ def parse_args(argv=None):
     ap.add_argument("--hybrid", action="store_true", help="EXTENSION (not in the reference; SURVEY 8d config 3 run B): the analytic scene "
                     "(floor, glass / mirror / diffuse spheres) with the mesh added to it, reference default camera")
     ap.add_argument("--gi-bounces", type=int, default=1, help="EXTENSION: diffuse bounces of the analytic / hybrid GI path (configs[2]: 4)")
-    ap.add_argument("--parity-window", default="64x32", help="WxH of the oracle window around the frame centre that the last timed frame is compared "
+    ap.add_argument("--parity-window", default="256x128", help="WxH of the oracle window around the frame centre that the last timed frame is compared "
                     "with after the timed run (full history chain from frame 0, all host threads); 0 = skip the parity block")
     ap.add_argument("--no-run-b", action="store_true", help="skip the short side measurement of BASELINE configs[2] as written (\"run B\": bunny + glass + mirror, "
                     "16 spp, 4 bounces -- the labelled hybrid EXTENSION) that the default line carries in `extension_run_b`")
