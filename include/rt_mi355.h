@@ -329,7 +329,9 @@ const char *rt_stage_name(int stage);
  * 7 a/b, 8 sqrt(a), 9 1/sqrt(a)).  Arrays are host memory of n floats (out: n uint32 bit patterns). */
 int rt_debug_eval(RtContext *ctx, int op, const float *a, const float *b, const float *c, uint32_t *out, int n);
 /* Trace n rays against the uploaded BVH with the device traversal: kind 0 = closest hit (out: t, then
- * hit point xyz, then normal xyz; t = inf on miss), kind 1 = any hit within tMax (out[0] = 1/0). */
+ * hit point xyz, then normal xyz; t = inf on miss), kind 1 = any hit within tMax (out[0] = 1/0).
+ * kinds 2 / 3: the same two questions put to the wavefront pipeline's own traversal kernels (persistent launch, refill scheduler, the
+ * any-hit node form rt_upload_bvh chose) -- kind 2: out[0] = t (inf on miss), out[1] = index of the triangle hit; kind 3: out[0] = 1/0. */
 int rt_debug_trace(RtContext *ctx, int kind, const float *origins, const float *dirs, const float *tMax, float eps,
                    float inf, float *out7, int n);
 

@@ -1316,9 +1316,57 @@ int rt_debug_eval(RtContext *c, int op, const float *a, const float *b, const fl
     return RT_OK;
 }
 
+// kinds 2 / 3: the same rays through the wavefront pipeline's traversal kernels (k_trace, as the frames launch it)
+static int debug_trace_wave(RtContext *c, bool any, const float *origins, const float *dirs, const float *tMax, float eps, float inf, float *out7, int n) {
+    if (c->nNodes <= 0 || c->nTris <= 0) return fail(c, RT_ERR_INVALID, "rt_debug_trace: no BVH uploaded");
+    std::vector<float> o4((size_t)n * 4, 0.0f), d4((size_t)n * 4, 0.0f), tm((size_t)n, inf);
+    for (int i = 0; i < n; ++i) {
+        std::memcpy(&o4[(size_t)i * 4], origins + (size_t)i * 3, 12);
+        std::memcpy(&d4[(size_t)i * 4], dirs + (size_t)i * 3, 12);
+        if (any) tm[(size_t)i] = tMax[i];
+    }
+    std::vector<unsigned char> hostBytes(sizeof(DevFrame), 0);
+    DevFrame *host = reinterpret_cast<DevFrame *>(hostBytes.data());
+    host->u.eps = eps; host->u.inf = inf;
+    host->sc = make_dev_scene(c);
+    host->giBounces = 1;
+    float4 *dO = nullptr, *dD = nullptr;
+    float *dT = nullptr, *dOutT = nullptr;
+    int *dTri = nullptr;
+    uint8_t *dOcc = nullptr;
+    uint32_t *dCnt = nullptr, *dHeads = nullptr;
+    DevFrame *dF = nullptr;
+    auto freeAll = [&]() { for (void *p : {(void *)dO, (void *)dD, (void *)dT, (void *)dOutT, (void *)dTri, (void *)dOcc, (void *)dCnt, (void *)dHeads, (void *)dF}) if (p) (void)hipFree(p); };
+    bool ok = hipMalloc(&dO, (size_t)n * 16) == hipSuccess && hipMalloc(&dD, (size_t)n * 16) == hipSuccess && hipMalloc(&dT, (size_t)n * 4) == hipSuccess &&
+              hipMalloc(&dOutT, (size_t)n * 4) == hipSuccess && hipMalloc(&dTri, (size_t)n * 4) == hipSuccess && hipMalloc(&dOcc, (size_t)n) == hipSuccess &&
+              hipMalloc(&dCnt, 4) == hipSuccess && hipMalloc(&dHeads, rt_wave_head_words() * 4) == hipSuccess && hipMalloc(&dF, sizeof(DevFrame)) == hipSuccess;
+    const uint32_t un = (uint32_t)n;
+    ok = ok && hipMemcpy(dO, o4.data(), (size_t)n * 16, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(dD, d4.data(), (size_t)n * 16, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(dT, tm.data(), (size_t)n * 4, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(dCnt, &un, 4, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemset(dHeads, 0, rt_wave_head_words() * 4) == hipSuccess && hipMemset(dOcc, 0, (size_t)n) == hipSuccess && hipMemset(dTri, 0xff, (size_t)n * 4) == hipSuccess &&
+         hipMemcpy(dF, host, sizeof(DevFrame), hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) { freeAll(); return fail(c, RT_ERR_HIP, "rt_debug_trace: allocation / upload failed"); }
+    rt_wave_debug_trace(c->stream, c->cus, c->treeDepth, dF, host->sc, any, dO, dD, dT, dCnt, un, dOutT, dTri, dOcc, dHeads);
+    std::vector<float> t((size_t)n);
+    std::vector<int> tri((size_t)n);
+    std::vector<uint8_t> occ((size_t)n);
+    ok = hipGetLastError() == hipSuccess && sync_all(c) == hipSuccess && hipMemcpy(t.data(), dOutT, (size_t)n * 4, hipMemcpyDeviceToHost) == hipSuccess &&
+         hipMemcpy(tri.data(), dTri, (size_t)n * 4, hipMemcpyDeviceToHost) == hipSuccess && hipMemcpy(occ.data(), dOcc, (size_t)n, hipMemcpyDeviceToHost) == hipSuccess;
+    freeAll();
+    if (!ok) return fail(c, RT_ERR_HIP, "rt_debug_trace: launch failed");
+    for (int i = 0; i < n; ++i) {
+        float *out = out7 + (size_t)i * 7;
+        for (int k = 0; k < 7; ++k) out[k] = 0.0f;
+        if (any) out[0] = occ[(size_t)i] ? 1.0f : 0.0f;
+        else { out[0] = tri[(size_t)i] >= 0 ? t[(size_t)i] : inf; out[1] = (float)tri[(size_t)i]; }   // closest: t and the triangle's index in the reference order
+    }
+    return RT_OK;
+}
+
 int rt_debug_trace(RtContext *c, int kind, const float *origins, const float *dirs, const float *tMax, float eps, float inf, float *out7, int n) {
-    if (!c || !origins || !dirs || !out7 || n <= 0 || (kind == 1 && !tMax)) return RT_ERR_INVALID;
+    if (!c || !origins || !dirs || !out7 || n <= 0 || ((kind == 1 || kind == 3) && !tMax) || kind < 0 || kind > 3) return RT_ERR_INVALID;
     (void)hipSetDevice(c->cfg.device);
+    if (kind >= 2) return guarded(c, "rt_debug_trace", [&]() -> int { return debug_trace_wave(c, kind == 3, origins, dirs, tMax, eps, inf, out7, n); });
     float *dO = nullptr, *dD = nullptr, *dT = nullptr, *dOut = nullptr;
     HIP_TRY(c, hipMalloc(&dO, (size_t)n * 12));
     HIP_TRY(c, hipMalloc(&dD, (size_t)n * 12));

@@ -1863,6 +1863,18 @@ void rt_wave_trace_closest_compact(hipStream_t st, int cus, int treeDepth, const
     TraceTune tune{32, 16, 0, 2, 0, 0, 0, 2, 0, 1, 0, 768, 1, -1};
     launch_trace<CompactSrc, false>(st, cus, 100, treeDepth, dFrame, hostScene, q, heads, nullptr, nullptr, tune, nullptr);
 }
+// Diagnostics (rt_debug_trace kinds 2 / 3): n arbitrary rays through the PRODUCTION traversal kernels -- a one-slot queue of n entries, closest-hit or any-hit
+// launch as the frames use it (persistent grid, refill scheduler, the any-hit node form rt_upload_bvh chose) -- so that the kernels can be tested ray by ray.
+void rt_wave_debug_trace(hipStream_t st, int cus, int treeDepth, const DevFrame *dFrame, const DevScene &hostScene, bool any, const float4 *o, const float4 *d,
+                         const float *tm, const uint32_t *liveCount, uint32_t n, float *outT, int *outTri, uint8_t *outOcc, uint32_t *heads) {
+    QueueSrc q;
+    q.o = o; q.d = d; q.tm = tm; q.liveCount = liveCount; q.c0 = 0; q.cap = n; q.stride = n; q.slots = 1; q.denseSlots = 0;
+    q.outT = outT; q.outTri = outTri; q.outOcc = outOcc; q.nLive = 0;
+    TraceTune tune{32, 16, 0, 2, 0, 0, 0, 2, 0, 1, 0, 768, 1, -1};
+    if (const char *e = getenv("RT_QNODES")) tune.qnodes = atoi(e);
+    if (any) launch_trace<QueueSrc, true>(st, cus, 100, treeDepth, dFrame, hostScene, q, heads, nullptr, nullptr, tune, nullptr);
+    else launch_trace<QueueSrc, false>(st, cus, 100, treeDepth, dFrame, hostScene, q, heads, nullptr, nullptr, tune, nullptr);
+}
 size_t rt_wave_head_words() { return kHeadWords; }
 
 int rt_wave_traced(RtWave *w, hipStream_t st, unsigned long long *out8, bool reset) {   // 16 words, see rt_wave.hpp

@@ -41,6 +41,8 @@ void rt_wave_trace_closest_indexed(hipStream_t st, int cus, int treeDepth, const
 // Nothing is traced when *flags has bit 2 or 4 set (rt_hybrid.hip: a pass that outgrew its arrays left the queue incomplete).
 void rt_wave_trace_closest_compact(hipStream_t st, int cus, int treeDepth, const rtd::DevFrame *dFrame, const rtd::DevScene &hostScene, const float4 *o, const float4 *d,
                                    const uint32_t *dst, const uint32_t *count, const uint32_t *flags, uint32_t cap, float *outT, int *outTri, uint32_t *heads);
+void rt_wave_debug_trace(hipStream_t st, int cus, int treeDepth, const rtd::DevFrame *dFrame, const rtd::DevScene &hostScene, bool any, const float4 *o, const float4 *d,
+                         const float *tm, const uint32_t *liveCount, uint32_t n, float *outT, int *outTri, uint8_t *outOcc, uint32_t *heads);
 size_t rt_wave_head_words();
 
 // rt_hybrid.hip -- EXTENSION: the hybrid scene (analytic objects + mesh, N diffuse bounces) in stages: shading passes that replay answered mesh

@@ -101,6 +101,83 @@ def test_traversal_matches_oracle_ray_by_ray(ren, orc):
     assert np.array_equal(got[:, 0], want)
 
 
+@pytest.mark.parametrize("qn", [0, 2])
+def test_wavefront_traversal_kernels_ray_by_ray_on_adversarial_rays(orc, monkeypatch, qn):
+    """rt_debug_trace kinds 2 / 3: arbitrary rays through the PRODUCTION traversal kernels (k_trace: persistent launch, refill scheduler, 4-wide any-hit
+    nodes -- exact and, with RT_QNODES=2, quantised), answer by answer against the oracle's restatement of traceBVH / traceBVHShadow.  Besides random rays:
+    axis-parallel rays (1/0 = inf slabs) whose origin coordinates sit EXACTLY on planes of node boxes, rays that start on triangle vertices and edge
+    midpoints (what shadow and AO rays do), rays aimed at box corners, rays with denormal-size direction components.  The quantised form must return the
+    same bits: its inner boxes only ever ADD candidates, the exact box test at the leaf decides."""
+    monkeypatch.setenv("RT_QNODES", str(qn))
+    nodes, tris = scenes.bunny_bvh(4)   # 5120 triangles, depth-12 tree
+    u = rt.frame_uniforms(rt.default_render_params(), rt.default_camera(), 64, 64, 0, True, nodes.shape[0], tris.shape[0])
+    rng = np.random.default_rng(11)
+    lo, hi = nodes[:, 0:3], nodes[:, 4:7]
+    centre = ((lo[0] + hi[0]) * 0.5).astype(np.float32)
+    ext = float((hi[0] - lo[0]).max())
+    f32 = np.float32
+
+    def unit(v):
+        v = v.astype(np.float32)
+        return (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
+
+    O, D = [], []
+    n = 6000
+    # (1) random rays towards the mesh
+    o = (centre + rng.normal(size=(n, 3)) * ext).astype(f32)
+    O.append(o); D.append(unit(centre + rng.uniform(-0.4, 0.4, (n, 3)) * ext - o))
+    # (2) axis-parallel rays lying exactly in planes of node boxes (two coordinates of the origin taken from box corners of random nodes)
+    for axis in range(3):
+        k = rng.integers(0, nodes.shape[0], n)
+        corner = np.where(rng.random((n, 3)) < 0.5, lo[k], hi[k]).astype(f32)
+        o = corner.copy()
+        o[:, axis] = (centre[axis] + np.where(rng.random(n) < 0.5, -1.0, 1.0) * ext * 1.5).astype(f32)
+        d = np.zeros((n, 3), f32)
+        d[:, axis] = -np.sign(o[:, axis] - centre[axis])
+        O.append(o); D.append(d)
+    # (3) rays leaving triangle vertices and edge midpoints
+    k = rng.integers(0, tris.shape[0], n)
+    v0, e1, e2 = tris[k, 0:3], tris[k, 4:7], tris[k, 8:11]
+    start = np.where((rng.random(n) < 0.5)[:, None], v0, (v0 + f32(0.5) * e1).astype(f32)).astype(f32)
+    O.append(start); D.append(unit(rng.normal(size=(n, 3))))
+    # (4) rays aimed exactly at corners of node boxes
+    k = rng.integers(0, nodes.shape[0], n)
+    corner = np.where(rng.random((n, 3)) < 0.5, lo[k], hi[k]).astype(f32)
+    o = (centre + unit(rng.normal(size=(n, 3))) * ext * 2.0).astype(f32)
+    O.append(o); D.append(unit(corner - o))
+    # (5) direction components of denormal size and exact zeros mixed in
+    o = (centre + rng.normal(size=(n, 3)) * ext).astype(f32)
+    d = unit(centre - o)
+    tiny = rng.integers(0, 3, n)
+    d[np.arange(n), tiny] = np.where(rng.random(n) < 0.5, f32(1e-41), f32(-0.0))
+    O.append(o); D.append(d)
+    org, dirs = np.concatenate(O).astype(f32), np.concatenate(D).astype(f32)
+    N = org.shape[0]
+    tmax = rng.uniform(0.05, 3.0, N).astype(f32) * f32(ext)
+    with rt.Renderer(pipeline=rt.RT_PIPELINE_WAVEFRONT) as r:
+        r.upload_bvh(nodes, tris)
+        closest = r.debug_trace(2, org, dirs)
+        anyhit = r.debug_trace(3, org, dirs, tmax)
+        ref_any = r.debug_trace(1, org, dirs, tmax)          # the megakernel's walk of the same question
+    hits = occluded = 0
+    for i in range(N):
+        hit, t, p, nn, _ = orc.trace_bvh(u, nodes, tris, org[i], dirs[i])
+        if hit:
+            hits += 1
+            assert closest[i, 0].view(np.uint32) == np.float32(t).view(np.uint32), (qn, i)
+            tri = int(closest[i, 1])
+            g = np.cross(tris[tri, 4:7].astype(np.float64), tris[tri, 8:11].astype(np.float64))
+            g /= np.linalg.norm(g)
+            assert abs(abs(float(np.dot(g, nn.astype(np.float64)))) - 1.0) < 1e-4, (qn, i, tri)     # the triangle the oracle's normal belongs to
+        else:
+            assert closest[i, 0] == np.float32(1e30), (qn, i)
+        occ = orc.trace_bvh_shadow(u, nodes, tris, org[i], dirs[i], tmax[i])
+        occluded += occ
+        assert bool(anyhit[i, 0]) == occ, (qn, i)
+    assert np.array_equal(anyhit[:, 0], ref_any[:, 0])
+    assert hits > N // 5 and occluded > N // 10
+
+
 @pytest.mark.parametrize("env", [None, "Sky_16", "tiny"])
 def test_analytic_scene_frames(ren, orc, env):
     """BASELINE config 1 (analytic 256x256) through the HIP path, frames 0..3 with TAA history."""
