@@ -101,15 +101,20 @@ def test_traversal_matches_oracle_ray_by_ray(ren, orc):
     assert np.array_equal(got[:, 0], want)
 
 
-@pytest.mark.parametrize("qn", [0, 2])
+@pytest.mark.parametrize("qn", [0, 2, "million"])
 def test_wavefront_traversal_kernels_ray_by_ray_on_adversarial_rays(orc, monkeypatch, qn):
     """rt_debug_trace kinds 2 / 3: arbitrary rays through the PRODUCTION traversal kernels (k_trace: persistent launch, refill scheduler, 4-wide any-hit
     nodes -- exact and, with RT_QNODES=2, quantised), answer by answer against the oracle's restatement of traceBVH / traceBVHShadow.  Besides random rays:
     axis-parallel rays (1/0 = inf slabs) whose origin coordinates sit EXACTLY on planes of node boxes, rays that start on triangle vertices and edge
     midpoints (what shadow and AO rays do), rays aimed at box corners, rays with denormal-size direction components.  The quantised form must return the
     same bits: its inner boxes only ever ADD candidates, the exact box test at the leaf decides."""
-    monkeypatch.setenv("RT_QNODES", str(qn))
-    nodes, tris = scenes.bunny_bvh(4)   # 5120 triangles, depth-12 tree
+    if qn == "million":                 # the 1 M-triangle scene with the form rt_upload_bvh chooses for it by itself (quantised: 9.8 MB of exact nodes)
+        monkeypatch.delenv("RT_QNODES", raising=False)
+        v_, f_ = rt.meshgen.million_triangle_scene()
+        nodes, tris = rt.build_bvh(rt.gather_triangles(v_, f_, np.eye(4, dtype=np.float32).reshape(-1)))
+    else:
+        monkeypatch.setenv("RT_QNODES", str(qn))
+        nodes, tris = scenes.bunny_bvh(4)   # 5120 triangles, depth-12 tree
     u = rt.frame_uniforms(rt.default_render_params(), rt.default_camera(), 64, 64, 0, True, nodes.shape[0], tris.shape[0])
     rng = np.random.default_rng(11)
     lo, hi = nodes[:, 0:3], nodes[:, 4:7]
@@ -175,7 +180,7 @@ def test_wavefront_traversal_kernels_ray_by_ray_on_adversarial_rays(orc, monkeyp
         occluded += occ
         assert bool(anyhit[i, 0]) == occ, (qn, i)
     assert np.array_equal(anyhit[:, 0], ref_any[:, 0])
-    assert hits > N // 5 and occluded > N // 10
+    assert hits > N // 8 and occluded > N // 16
 
 
 @pytest.mark.parametrize("env", [None, "Sky_16", "tiny"])
