@@ -55,7 +55,7 @@ def test_bench_line_contract():
     assert pz["vs"] == "oracle" and pz["ok"] is True and pz["rmse"] < 1e-4 and pz["bit_diff"] == 0 and pz["outliers_gt_1e-2"] == 0
     assert pz["frames_chained"] == 8 and pz["frame"] == 7 and set(pz["targets"]) == {"color", "motion", "gpos", "gnrm"}
     x0, y0, x1, y1 = pz["window"]
-    assert (x1 - x0, y1 - y0) == (64, 32) and x0 <= 320 < x1 and y0 <= 180 < y1
+    assert (x1 - x0, y1 - y0) == (256, 128) and x0 <= 320 < x1 and y0 <= 180 < y1
     b = d["cpu_baseline"]
     assert b["kind"] == "port" and b["cores"] >= 1 and b["value"] > 0 and b["single_thread"]["cores"] == 1 and b["single_thread"]["value"] > 0
     assert "-O3 -march=native" in b["sample"]
