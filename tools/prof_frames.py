@@ -14,6 +14,7 @@ ap.add_argument("--spp", type=int, default=4)
 ap.add_argument("--subdiv", type=int, default=6)
 ap.add_argument("--size", default="1920x1080")
 ap.add_argument("--scene", default="bunny")
+ap.add_argument("--objects", type=int, default=16, help="--scene 1m: number of displaced spheres (62 500 triangles each; 16 = the 1 M-triangle scene)")
 ap.add_argument("--world", type=int, default=1)
 ap.add_argument("--rank", type=int, default=0)
 ap.add_argument("--batch", type=int, default=1, help="frames per rt_render_frames call (bench.py's default is 8)")
@@ -21,7 +22,7 @@ a = ap.parse_args()
 W, H = map(int, a.size.split("x"))
 import time
 if a.scene == "1m":
-    t0 = time.time(); v, f = rt.meshgen.million_triangle_scene(); tris9 = rt.gather_triangles(v, f, np.eye(4, dtype=np.float32).T.reshape(-1)); nodes, tris = rt.build_bvh(tris9)
+    t0 = time.time(); v, f = rt.meshgen.million_triangle_scene(a.objects); tris9 = rt.gather_triangles(v, f, np.eye(4, dtype=np.float32).T.reshape(-1)); nodes, tris = rt.build_bvh(tris9)
     print('1M scene', tris.shape, nodes.shape, 'built in', round(time.time() - t0, 1), 's')
 else:
     nodes, tris = scenes.bunny_bvh(a.subdiv)
