@@ -44,6 +44,9 @@ struct RtContext {
     // scene
     float4 *dWNodes = nullptr, *dW4 = nullptr, *dTris = nullptr, *dWNodesW = nullptr, *dPairs = nullptr;
     float4 *dQ4 = nullptr, *dLeafBox = nullptr;   // RT_QNODES: quantised any-hit nodes + the leaves' exact boxes
+    float4 *dWF = nullptr;           // fused closest-hit records (round 5), null when the tree's boxes are not the unions of their children's
+    size_t nFused = 0;
+    int sceneFlags = 0;              // RT_SCENE_* bits of RtSceneInfo.flags
     int rootRefW = 0;
     void *dHistAll[RT_MAX_LANES] = {};      // tile-parallel + moving camera: every rank's COLOR0 block of the frame a lane rendered
     bool histExchanged[RT_MAX_LANES] = {};
@@ -223,6 +226,7 @@ DevScene make_dev_scene(const RtContext *c) {
     s.leafBox = c->dLeafBox;
     s.leafBoxMagic = c->leafBoxMagic;
     s.wnodesW = c->dWNodesW;
+    s.wF = c->dWF;
     s.pairs = c->dPairs;
     s.rootRefW = c->rootRefW;
     s.tris = c->dTris;
@@ -401,6 +405,7 @@ void rt_destroy(RtContext *c) {
     if (c->dQ4) (void)hipFree(c->dQ4);
     if (c->dLeafBox) (void)hipFree(c->dLeafBox);
     if (c->dWNodesW) (void)hipFree(c->dWNodesW);
+    if (c->dWF) (void)hipFree(c->dWF);
     if (c->dPairs) (void)hipFree(c->dPairs);
     if (c->dTris) (void)hipFree(c->dTris);
     if (c->dEnv) (void)hipFree(c->dEnv);
@@ -422,12 +427,14 @@ int rt_upload_bvh(RtContext *c, const float *nodes12, int nNodes, const float *t
     if (c->dQ4) (void)hipFree(c->dQ4);
     if (c->dLeafBox) (void)hipFree(c->dLeafBox);
     if (c->dWNodesW) (void)hipFree(c->dWNodesW);
+    if (c->dWF) (void)hipFree(c->dWF);
     if (c->dPairs) (void)hipFree(c->dPairs);
     if (c->dTris) (void)hipFree(c->dTris);
-    c->dWNodes = c->dW4 = c->dTris = c->dWNodesW = c->dPairs = c->dQ4 = c->dLeafBox = nullptr;
+    c->dWNodes = c->dW4 = c->dTris = c->dWNodesW = c->dPairs = c->dQ4 = c->dLeafBox = c->dWF = nullptr;
     c->nNodes = c->nTris = c->nInner = 0;
     c->treeDepth = 0;
-    c->nWide4 = c->nPairs = 0;
+    c->nWide4 = c->nPairs = c->nFused = 0;
+    c->sceneFlags = 0;
     c->anyStack = 0;
     if (nNodes == 0 || nTris == 0) return RT_OK;
     if (nTris >= (1 << 28)) return fail(c, RT_ERR_UNSUPPORTED, "rt_upload_bvh: %d triangles exceed the 2^28 leaf encoding", nTris);
@@ -775,6 +782,7 @@ int rt_upload_bvh(RtContext *c, const float *nodes12, int nNodes, const float *t
             if (getenv("RT_QNODES_SPARSE_BOXES")) rmin = 1;      // EXPERIMENT: one slot per pair record, as first built
             c->leafBoxMagic = rmin <= 1 ? 0u : (uint32_t)((((uint64_t)1 << 32) + (uint64_t)rmin - 1) / (uint64_t)rmin);
             leafBox.assign(((pairs.size() / 20) / (size_t)std::max(rmin, 1) + 1) * 8, 0.0f);
+            std::vector<char> taken(leafBox.size() / 8, 0);   // (host only: nothing but boxes is uploaded)
             c->nLeafBoxes = 0;
             for (int i = 0; i < nNodes; ++i) if (nd[(size_t)i].count > 0) {
                 ++c->nLeafBoxes;
@@ -782,12 +790,78 @@ int rt_upload_bvh(RtContext *c, const float *nodes12, int nNodes, const float *t
                 const size_t at = c->leafBoxMagic ? (size_t)(((uint64_t)first * c->leafBoxMagic) >> 32) : first;
                 const float *b = nodes12 + (size_t)i * 12;
                 const float box[8] = {b[0], b[1], b[2], b[4], b[5], b[6], 0.0f, 0.0f};
-                if (at * 8 + 8 > leafBox.size() || leafBox[at * 8 + 6] != 0.0f) { okQ = false; break; }   // (cannot happen: distinct quotients)
+                if (at * 8 + 8 > leafBox.size() || taken[at]) { okQ = false; break; }   // (cannot happen: distinct quotients)
                 std::memcpy(&leafBox[at * 8], box, sizeof box);
-                leafBox[at * 8 + 6] = 1.0f;                                                                  // slot taken
+                taken[at] = 1;
             }
             if (!okQ) { q4.clear(); leafBox.clear(); }
         } else q4.clear();
+        if (!okQ) {   // asked for and not built: say so instead of falling back silently
+            c->sceneFlags |= RT_SCENE_QNODES_REJECTED;
+            if (getenv("RT_VERBOSE")) fprintf(stderr, "[rt_upload_bvh] quantised any-hit nodes rejected (exponent range or leaf-box index collision): walking the exact 112-byte nodes\n");
+        }
+    }
+    // Round 5 -- fused closest-hit records.  The closest-hit walk must keep the reference's visiting order (rt_bvh.glsl:205-241: near child first, far
+    // child behind the pop-time cull; ties and triangles a rounding in front of their leaf box make the answer depend on it), but nothing says it
+    // must spend one dependent memory round trip per binary node.  Whenever the walk enters a child X of a node N it visits X next, and X's record (the
+    // boxes of X's children) is known as soon as N's index is -- so the records of N's two children are stored TOGETHER under N's index, 128 bytes = one
+    // cache line per even-level inner node N ("hub"):
+    //     pieces 0-3: [A1.min, ref A1] [A1.max, ref A2] [A2.min, -] [A2.max, -]      A = N.left,  A1 / A2 = A's children
+    //     pieces 4-7: the same for B = N.right
+    // A leaf child X is stored as a half with ONE box: [X.min, leaf ref] [X.max, RT_NO_CHILD] [NaN box].  References are hub indices (>= 0) or the pair-record
+    // leaf codes of wnodesW (< 0).  The kernel (k_trace<.., FUSE>) fetches the eight pieces in one round trip and makes the reference's two steps from them:
+    // the step at N needs the boxes of A and B themselves, which are not stored -- they are the unions of their children's boxes, and the slab values of a
+    // union follow from the children's by min / max (per axis: tsm = min(tsm1, tsm2), tbg = max(tbg1, tbg2); tests/test_fused_nodes.py pins that identity
+    // against the slab test of the union box, signed zeros, infinities and the NaN of 0 * inf included).  That needs every inner box to BE the union of its children's, bit for bit --
+    // true of the reference's builder (bounds over a range = the union of the bounds over its halves, bvh.cpp:41-60) and of rt_build_bvh_gpu, checked
+    // here for whatever was uploaded; a tree that fails the check keeps the 64-byte records (RT_SCENE_NOT_FUSED in RtSceneInfo.flags).
+    std::vector<float> wF;
+    {
+        bool okF = nd[0].count <= 0 && !(getenv("RT_FUSED_BUILD") && atoi(getenv("RT_FUSED_BUILD")) == 0);   // RT_FUSED_BUILD=0: tests of the fallback
+        for (int i = 0; i < nNodes && okF; ++i) {
+            if (nd[(size_t)i].count > 0) continue;
+            const float *P = nodes12 + (size_t)i * 12, *L = nodes12 + (size_t)nd[(size_t)i].left * 12, *R = nodes12 + (size_t)nd[(size_t)i].right * 12;
+            for (int a = 0; a < 3; ++a)
+                if (!(P[a] == std::min(L[a], R[a])) || !(P[4 + a] == std::max(L[4 + a], R[4 + a]))) okF = false;
+        }
+        if (okF) {
+            struct Job { int bin; size_t at; };
+            std::vector<Job> jobs{{0, 0}};
+            wF.resize(32, 0.0f);
+            const float qnan = std::nanf("");
+            while (!jobs.empty()) {
+                const Job jb = jobs.back();
+                jobs.pop_back();
+                for (int h = 0; h < 2; ++h) {
+                    const int X = h == 0 ? nd[(size_t)jb.bin].left : nd[(size_t)jb.bin].right;
+                    int kids[2] = {X, -1};
+                    if (nd[(size_t)X].count <= 0) { kids[0] = nd[(size_t)X].left; kids[1] = nd[(size_t)X].right; }
+                    int refs[2] = {RT_NO_CHILD, RT_NO_CHILD};
+                    for (int k = 0; k < 2; ++k) {
+                        float box[6] = {qnan, qnan, qnan, qnan, qnan, qnan};
+                        if (kids[k] >= 0) {
+                            const float *b = nodes12 + (size_t)kids[k] * 12;
+                            box[0] = b[0]; box[1] = b[1]; box[2] = b[2]; box[3] = b[4]; box[4] = b[5]; box[5] = b[6];
+                            if (nd[(size_t)kids[k]].count > 0) refs[k] = refOfW(kids[k]);
+                            else {
+                                refs[k] = (int)(wF.size() / 32);
+                                if ((size_t)refs[k] >= ((size_t)1 << 29)) { okF = false; break; }
+                                wF.resize(wF.size() + 32, 0.0f);
+                                jobs.push_back({kids[k], (size_t)refs[k]});
+                            }
+                        }
+                        float *o = &wF[jb.at * 32 + (size_t)h * 16 + (size_t)k * 8];
+                        o[0] = box[0]; o[1] = box[1]; o[2] = box[2]; o[4] = box[3]; o[5] = box[4]; o[6] = box[5];
+                    }
+                    if (!okF) break;
+                    float *o = &wF[jb.at * 32 + (size_t)h * 16];
+                    std::memcpy(&o[3], &refs[0], 4);
+                    std::memcpy(&o[7], &refs[1], 4);
+                }
+                if (!okF) break;
+            }
+        }
+        if (!okF) { wF.clear(); if (nd[0].count <= 0) c->sceneFlags |= RT_SCENE_NOT_FUSED; }
     }
     if (depth > 32) return fail(c, RT_ERR_UNSUPPORTED, "rt_upload_bvh: tree depth %d exceeds the 32-entry traversal stack", depth);
     if (!q4.empty()) {
@@ -795,6 +869,11 @@ int rt_upload_bvh(RtContext *c, const float *nodes12, int nNodes, const float *t
         HIP_TRY(c, hipMemcpy(c->dQ4, q4.data(), q4.size() * 4, hipMemcpyHostToDevice));
         HIP_TRY(c, hipMalloc(&c->dLeafBox, leafBox.size() * 4));
         HIP_TRY(c, hipMemcpy(c->dLeafBox, leafBox.data(), leafBox.size() * 4, hipMemcpyHostToDevice));
+    }
+    if (!wF.empty()) {
+        HIP_TRY(c, hipMalloc(&c->dWF, wF.size() * sizeof(float)));
+        HIP_TRY(c, hipMemcpy(c->dWF, wF.data(), wF.size() * sizeof(float), hipMemcpyHostToDevice));
+        c->nFused = wF.size() / 32;
     }
     HIP_TRY(c, hipMalloc(&c->dWNodes, wn.size() * sizeof(float)));
     HIP_TRY(c, hipMalloc(&c->dW4, w4.size() * sizeof(float)));
@@ -1239,6 +1318,8 @@ int rt_get_scene_info(const RtContext *c, RtSceneInfo *out) {
     out->bytesNodes4 = c->dQ4 ? (uint64_t)c->nWide4 * 64 + (uint64_t)c->nLeafBoxes * 32 : (uint64_t)c->nWide4 * 128;   // the any-hit launches walk the quantised nodes when they exist
     out->bytesPairs = (uint64_t)c->nPairs * 80;
     out->bytesTris = (uint64_t)c->nTris * 48;
+    out->nFused = (int32_t)c->nFused;
+    out->flags = c->sceneFlags;
     return RT_OK;
 }
 

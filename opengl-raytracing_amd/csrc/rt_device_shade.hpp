@@ -33,6 +33,7 @@ struct DevScene {
     const float4 *leafBox;   // RT_QNODES: 2 x float4 per leaf: its exact box [lo.xyz hi.x][hi.yz - -], at index (first pair record * leafBoxMagic) >> 32
     uint32_t leafBoxMagic;   // ceil(2^32 / R), R = fewest pair records of a leaf (0: index = first pair record), see rt_upload_bvh
     const float4 *wnodesW;   // wnodes with pair-record leaf references (wavefront closest-hit kernels)
+    const float4 *wF;        // fused closest-hit records (round 5): 8 x float4 per even-level inner node = the wnodesW records of its two children, see rt_upload_bvh (null: not built)
     const float4 *pairs;     // 5 x float4 per PAIR of triangles of a leaf: [v0 e1 e2][v0 e1 e2][index of the first][-], see rt_upload_bvh
     const float4 *tris;
     const uchar4 *env;

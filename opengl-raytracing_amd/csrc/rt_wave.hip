@@ -481,7 +481,41 @@ RT_DEV uint32_t quad_distinct(uint32_t key) {
 constexpr uint32_t kShards = 64, kShardStride = 32;   // cursor shards per trace launch, uint32 words between them (128 B)
 constexpr uint32_t kHeadWords = kShards * kShardStride;
 
-struct TraceTune { int refillMin; int minSearch; int chunk; int leafb; int skipTraversal; int quadRefill; int coop; int leafbClosest; int nearFirst; int reverse; int guided; int chunkMax; int denseTake; int qnodes; };   // skipTraversal: diagnostic (RT_DEBUG_SKIP_TRAVERSAL)
+struct TraceTune { int refillMin; int minSearch; int chunk; int leafb; int skipTraversal; int quadRefill; int coop; int leafbClosest; int nearFirst; int reverse; int guided; int chunkMax; int denseTake; int qnodes; int fused; };   // skipTraversal: diagnostic (RT_DEBUG_SKIP_TRAVERSAL)
+// fused (RT_FUSED=1, measured option of round 5, off): closest-hit launches walk the fused records (DevScene::wF) when rt_upload_bvh built them -- the reference's
+// visiting order in half the dependent round trips (bounce rays: 20.6 -> 11.2 steps, primary 17.1 -> 9.7), bit-identical, and 3-4 % SLOWER in every mode (batched,
+// frame by frame, one rank of eight): the same number of 16-byte lane-loads per ray, and that number -- not the length of the dependency chain -- is what these
+// launches cost (profiles/r05_experiments.txt 1)
+static TraceTune default_tune() {
+    TraceTune t{32, 16, 0, 2, 0, 0, 0, 2, 0, 1, 0, 768, 1, -1, 0};
+    if (const char *e = getenv("RT_FUSED")) t.fused = atoi(e);
+    return t;
+}
+
+// The slab test of rt_bvh.glsl:124-134 in two halves, so that the per-axis values of two child boxes can be merged into their parent's (k_trace, FUSE):
+// slab_parts + slab_eval are slab() operation for operation.
+struct SlabP { float sx, sy, sz, bx, by, bz; };
+RT_DEV SlabP slab_parts(V3 ro, V3 rdInv, V3 bmin, V3 bmax) {
+    const V3 t0 = (bmin - ro) * rdInv, t1 = (bmax - ro) * rdInv;
+    SlabP p;
+    p.sx = fminr(t0.x, t1.x); p.sy = fminr(t0.y, t1.y); p.sz = fminr(t0.z, t1.z);
+    p.bx = fmaxr(t0.x, t1.x); p.by = fmaxr(t0.y, t1.y); p.bz = fmaxr(t0.z, t1.z);
+    return p;
+}
+RT_DEV bool slab_eval(const SlabP &p, float &tminOut) {
+    const float tmin = fmaxr(fmaxr(p.sx, p.sy), fmaxr(p.sz, 0.0f));
+    const float tmax = fminr(fminr(p.bx, p.by), p.bz);
+    tminOut = tmin;
+    return tmax >= tmin;
+}
+// the parts of the box min(a.min, b.min) .. max(a.max, b.max): (x - ro) * rdInv is monotone in x, so the union's near / far plane distances are the smaller / larger
+// of the two boxes' (v_min / v_max drop the NaN of 0 * inf and of an absent child's NaN box exactly as the direct evaluation does: tests/test_fused_nodes.py)
+RT_DEV SlabP slab_union(const SlabP &a, const SlabP &b) {
+    SlabP p;
+    p.sx = fminr(a.sx, b.sx); p.sy = fminr(a.sy, b.sy); p.sz = fminr(a.sz, b.sz);
+    p.bx = fmaxr(a.bx, b.bx); p.by = fmaxr(a.by, b.by); p.bz = fmaxr(a.bz, b.bz);
+    return p;
+}
 
 template <bool ANY> struct StackOf { typedef StackEntry type; };          // closest: {deferred child, its entry distance}
 template <> struct StackOf<true> { typedef uint32_t type; };              // any-hit: the pop-time cull never fires (tMax is constant)
@@ -495,7 +529,7 @@ extern __shared__ __align__(16) unsigned char rt_dyn_lds[];
 #ifndef RT_ANYHIT_WAVES
 #define RT_ANYHIT_WAVES 7   // any-hit launches: 72 VGPRs, seven waves per SIMD (with the exact stack size of rt_upload_bvh seven workgroups fit a CU's LDS)
 #endif
-template <class Src, bool ANY, int LEAFB, bool STATS = false, bool COOP = false, bool NEAR = false, int QN = 0>
+template <class Src, bool ANY, int LEAFB, bool STATS = false, bool COOP = false, bool NEAR = false, int QN = 0, bool FUSE = false>
 __global__ __launch_bounds__(256, (!STATS && !ANY) ? 5 : ((NEAR || QN == 2) ? 6 : (ANY && !STATS && LEAFB == 2 ? RT_ANYHIT_WAVES : 1))) void k_trace(const DevFrame *__restrict__ fr, const float4 *__restrict__ wnodes, const float4 *__restrict__ tris, Src src,
                                                 uint32_t *head, unsigned long long *tally, unsigned long long *gatherLoads, TraceTune tune,
                                                 int stackEntries, unsigned long long *stats = nullptr, const float4 *__restrict__ leafBox = nullptr) {
@@ -794,6 +828,63 @@ __global__ __launch_bounds__(256, (!STATS && !ANY) ? 5 : ((NEAR || QN == 2) ? 6 
                     take(h0, r0); take(h1, r1); take(h2, r2); take(h3, r3);
                     if (nxt == RT_NO_CHILD) pop_or_finish();
                     else ref = nxt;
+                } else if constexpr (FUSE) {
+                    // Fused records (round 5, rt_upload_bvh): `ref` names a hub N -- an even-level inner node whose 128-byte record holds the 64-byte records of its
+                    // two children A and B -- or, with kPair set, ONE of those children (a far child the step at N deferred).  A full step is the reference's step
+                    // at N (rt_bvh.glsl:226-239: both child boxes, near one first, far one deferred with its entry distance) followed at once by its step at the
+                    // near child X, from one round trip of eight loads; a pair step is the step at the deferred child alone (four loads).  The boxes of A and B are
+                    // the unions of their children's (checked at upload), so their slab values are merged from the grandchildren's: same floats, same decisions,
+                    // same visiting order as the two-wide walk below -- the stack holds what it would hold (one entry per binary level).
+                    constexpr uint32_t kPair = 0x40000000u, kHalfB = 0x20000000u, kIdx = 0x1fffffffu;
+                    const uint32_t code = (uint32_t)ref;
+                    const bool pairStep = (code & kPair) != 0u;
+                    const uint32_t hub = code & kIdx;
+                    const v4f *ndv = reinterpret_cast<const v4f *>(nodes + (size_t)hub * 8) + ((pairStep && (code & kHalfB)) ? 4 : 0);
+                    v4f x0 = ndv[0], x1 = ndv[1], x2 = ndv[2], x3 = ndv[3];     // the half the walk goes into (full step: A, swapped below when B is nearer)
+                    v4f y0 = {0, 0, 0, 0}, y1 = y0, y2 = y0, y3 = y0;
+                    if (!pairStep) { y0 = ndv[4]; y1 = ndv[5]; y2 = ndv[6]; y3 = ndv[7]; }
+                    pin(x0); pin(x1); pin(x2); pin(x3); pin(y0); pin(y1); pin(y2); pin(y3);
+                    gathers += pairStep ? 0u : 4u;      // (4 were counted above)
+                    SlabP pX1 = slab_parts(ro, rdInv, mk3(x0.x, x0.y, x0.z), mk3(x1.x, x1.y, x1.z));
+                    SlabP pX2 = slab_parts(ro, rdInv, mk3(x2.x, x2.y, x2.z), mk3(x3.x, x3.y, x3.z));
+                    int g1 = (int)f2u(x0.w), g2 = (int)f2u(x1.w);              // X's children (g2 == RT_NO_CHILD: X is a leaf, g1 its reference)
+                    bool enter = true;
+                    if (!pairStep) {
+                        const SlabP pY1 = slab_parts(ro, rdInv, mk3(y0.x, y0.y, y0.z), mk3(y1.x, y1.y, y1.z));
+                        const SlabP pY2 = slab_parts(ro, rdInv, mk3(y2.x, y2.y, y2.z), mk3(y3.x, y3.y, y3.z));
+                        float tA, tB;
+                        const bool hitA = slab_eval(slab_union(pX1, pX2), tA) && tA <= tBest;
+                        const bool hitB = slab_eval(slab_union(pY1, pY2), tB) && tB <= tBest;
+                        const bool goB = hitB && !(hitA && tA < tB);           // both hit: leftFirst = tA < tB (rt_bvh.glsl:232)
+                        enter = hitA || hitB;
+                        if (hitA && hitB) {                                     // defer the far child: a leaf as itself, an inner node as (hub, half)
+                            const int f1 = goB ? g1 : (int)f2u(y0.w), f2 = goB ? g2 : (int)f2u(y1.w);
+                            StackEntry e;
+                            e.x = f2 == RT_NO_CHILD ? (uint32_t)f1 : (kPair | (goB ? 0u : kHalfB) | hub);
+                            e.y = f2u(goB ? tA : tB);
+                            stk[sp * 64] = e;
+                            sp++;
+                        }
+                        if (goB) { pX1 = pY1; pX2 = pY2; g1 = (int)f2u(y0.w); g2 = (int)f2u(y1.w); }
+                    }
+                    if (!enter) pop_or_finish();
+                    else if (g2 == RT_NO_CHILD) ref = g1;                       // the near child is a leaf: the leaf phase takes it
+                    else {                                                      // the reference's step at the near child X
+                        float t1, t2;
+                        const bool h1 = slab_eval(pX1, t1) && t1 <= tBest;
+                        const bool h2 = slab_eval(pX2, t2) && t2 <= tBest;
+                        if (h1 && h2) {
+                            const bool leftFirst = t1 < t2;
+                            StackEntry e;
+                            e.x = (uint32_t)(leftFirst ? g2 : g1);
+                            e.y = f2u(leftFirst ? t2 : t1);
+                            stk[sp * 64] = e;
+                            sp++;
+                            ref = leftFirst ? g1 : g2;
+                        } else if (h1 || h2) {
+                            ref = h1 ? g1 : g2;
+                        } else pop_or_finish();
+                    }
                 } else {
                     const float4 *nd = nodes + (size_t)ref * 4;
                     const v4f *ndv = reinterpret_cast<const v4f *>(nd);
@@ -1421,7 +1512,8 @@ void launch_trace(hipStream_t st, int cus, int gridPct, int depth, const DevFram
     const int stack = std::max(4, ANY ? (hs.anyStack > 0 ? hs.anyStack : 3 * ((depth + 1) / 2)) : depth);
     const size_t ldsBytes = (size_t)256 * stack * (ANY ? 4 : 8);
     const bool qn = ANY && tune.qnodes != 0 && hs.q4 != nullptr && !stats && !tune.nearFirst;   // (the diagnostic and near-first builds walk the exact nodes)   // -1: whenever rt_upload_bvh built the quantised nodes (trees beyond the L2)
-    const float4 *nodes = ANY ? (qn ? hs.q4 : hs.w4) : hs.wnodesW;
+    const bool fuse = !ANY && tune.fused != 0 && hs.wF != nullptr && !tune.coop;   // closest-hit launches: the fused records when rt_upload_bvh built them
+    const float4 *nodes = ANY ? (qn ? hs.q4 : hs.w4) : (fuse ? hs.wF : hs.wnodesW);
     auto go = [&](auto kernel) {
         // the runtime's answer per (device, kernel, LDS bytes): a process may hold contexts on devices of different shapes
         thread_local std::map<std::tuple<int, const void *, size_t>, int> occ;
@@ -1436,7 +1528,9 @@ void launch_trace(hipStream_t st, int cus, int gridPct, int depth, const DevFram
         hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), ldsBytes, st, fr, nodes, hs.pairs, src, head, tally, gatherLoads, tune, stack, stats, hs.leafBox);
     };
     const int leafb = ANY ? tune.leafb : tune.leafbClosest;
-    if (stats) { if (leafb >= 4) go(k_trace<Src, ANY, 4, true>); else go(k_trace<Src, ANY, 2, true>); }
+    if (stats && fuse) go(k_trace<Src, ANY, 2, true, false, false, 0, !ANY>);
+    else if (stats) { if (leafb >= 4) go(k_trace<Src, ANY, 4, true>); else go(k_trace<Src, ANY, 2, true>); }
+    else if (fuse) go(k_trace<Src, ANY, 2, false, false, false, 0, !ANY>);
     else if (!ANY && tune.coop) go(k_trace<Src, ANY, 2, false, !ANY>);
     else if (ANY && tune.nearFirst) go(k_trace<Src, ANY, 2, false, false, ANY>);
     else if (qn && tune.qnodes == 1) go(k_trace<Src, ANY, 2, false, false, false, ANY ? 1 : 0>);   // seven waves per SIMD, 44 B of scratch: slower (measured)
@@ -1498,7 +1592,7 @@ struct RtWave {
     // ray-queue budget per frame lane; 288 GB of HBM make this cheap.  16 GB hold the queues of a whole batch of eight 1080p / 4 spp frames (7.4 M hits x
     // 2.1 KB) in ONE chunk: no hit-count read-back, half the launches (1.76-1.80 -> 1.68-1.72 ms per frame against 8 GB; profiles/r03_experiments.txt)
     size_t budgetBytes = (size_t)16 << 30;
-    TraceTune tune{32, 16, 0, 2, 0, 0, 0, 2, 0, 1, 0, 768, 1, -1};   // chunk 0 = run length chosen in the kernel from the queue size
+    TraceTune tune = default_tune();   // chunk 0 = run length chosen in the kernel from the queue size
     // allocations
     size_t slotsCap = 0;      // per-frame arrays sized for this many pixel slots
     size_t chunkBytes = 0;    // bytes of the per-chunk arena
@@ -1853,14 +1947,14 @@ void rt_wave_trace_closest_indexed(hipStream_t st, int cus, int treeDepth, const
                                    const uint32_t *count, const float4 *o, const float4 *d, float *outT, int *outTri, uint32_t *heads) {
     IndexedSrc q;
     q.idx = idx; q.count = count; q.o = o; q.d = d; q.outT = outT; q.outTri = outTri; q.n = 0;
-    TraceTune tune{32, 16, 0, 2, 0, 0, 0, 2, 0, 1, 0, 768, 1, -1};
+    TraceTune tune = default_tune();
     launch_trace<IndexedSrc, false>(st, cus, 100, treeDepth, dFrame, hostScene, q, heads, nullptr, nullptr, tune, nullptr);
 }
 void rt_wave_trace_closest_compact(hipStream_t st, int cus, int treeDepth, const DevFrame *dFrame, const DevScene &hostScene, const float4 *o, const float4 *d,
                                    const uint32_t *dst, const uint32_t *count, const uint32_t *flags, uint32_t cap, float *outT, int *outTri, uint32_t *heads) {
     CompactSrc q;
     q.o = o; q.d = d; q.dst = dst; q.count = count; q.flags = flags; q.cap = cap; q.outT = outT; q.outTri = outTri; q.n = 0;
-    TraceTune tune{32, 16, 0, 2, 0, 0, 0, 2, 0, 1, 0, 768, 1, -1};
+    TraceTune tune = default_tune();
     launch_trace<CompactSrc, false>(st, cus, 100, treeDepth, dFrame, hostScene, q, heads, nullptr, nullptr, tune, nullptr);
 }
 // Diagnostics (rt_debug_trace kinds 2 / 3): n arbitrary rays through the PRODUCTION traversal kernels -- a one-slot queue of n entries, closest-hit or any-hit
@@ -1870,7 +1964,7 @@ void rt_wave_debug_trace(hipStream_t st, int cus, int treeDepth, const DevFrame 
     QueueSrc q;
     q.o = o; q.d = d; q.tm = tm; q.liveCount = liveCount; q.c0 = 0; q.cap = n; q.stride = n; q.slots = 1; q.denseSlots = 0;
     q.outT = outT; q.outTri = outTri; q.outOcc = outOcc; q.nLive = 0;
-    TraceTune tune{32, 16, 0, 2, 0, 0, 0, 2, 0, 1, 0, 768, 1, -1};
+    TraceTune tune = default_tune();
     if (const char *e = getenv("RT_QNODES")) tune.qnodes = atoi(e);
     if (any) launch_trace<QueueSrc, true>(st, cus, 100, treeDepth, dFrame, hostScene, q, heads, nullptr, nullptr, tune, nullptr);
     else launch_trace<QueueSrc, false>(st, cus, 100, treeDepth, dFrame, hostScene, q, heads, nullptr, nullptr, tune, nullptr);

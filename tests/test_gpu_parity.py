@@ -101,13 +101,16 @@ def test_traversal_matches_oracle_ray_by_ray(ren, orc):
     assert np.array_equal(got[:, 0], want)
 
 
-@pytest.mark.parametrize("qn", [0, 2, "million"])
+@pytest.mark.parametrize("qn", [0, 2, "million", "fused"])
 def test_wavefront_traversal_kernels_ray_by_ray_on_adversarial_rays(orc, monkeypatch, qn):
     """rt_debug_trace kinds 2 / 3: arbitrary rays through the PRODUCTION traversal kernels (k_trace: persistent launch, refill scheduler, 4-wide any-hit
     nodes -- exact and, with RT_QNODES=2, quantised), answer by answer against the oracle's restatement of traceBVH / traceBVHShadow.  Besides random rays:
     axis-parallel rays (1/0 = inf slabs) whose origin coordinates sit EXACTLY on planes of node boxes, rays that start on triangle vertices and edge
     midpoints (what shadow and AO rays do), rays aimed at box corners, rays with denormal-size direction components.  The quantised form must return the
     same bits: its inner boxes only ever ADD candidates, the exact box test at the leaf decides."""
+    if qn == "fused":                   # round 5: the closest-hit launches on the fused records (RT_FUSED=1: the reference's order, two binary steps per round trip)
+        monkeypatch.setenv("RT_FUSED", "1")
+        qn = 0
     if qn == "million":                 # the 1 M-triangle scene with the form rt_upload_bvh chooses for it by itself (quantised: 9.8 MB of exact nodes)
         monkeypatch.delenv("RT_QNODES", raising=False)
         v_, f_ = rt.meshgen.million_triangle_scene()
@@ -309,6 +312,67 @@ def test_quantised_anyhit_nodes(orc, monkeypatch, qn, mesh, sah):
             want, _ = orc.render(u, nodes, tris, faces, prev)
             _assert_targets_equal(r.read_all(), want, orc, f"RT_QNODES={qn} sah={sah} {mesh} frame={f}")
             prev = want[0]
+
+
+@pytest.mark.parametrize("mesh,inflate", [("one_leaf", False), ("tiny", False), ("deep", False), ("deep", True)])
+def test_fused_closest_hit_records(orc, monkeypatch, mesh, inflate):
+    """RT_FUSED=1 (round 5, a measured option): the closest-hit launches walk 128-byte records that hold the 64-byte records of a node's two children, so that the
+    reference's step at a node and its step at the near child (rt_bvh.glsl:205-241) come out of one round trip; the children's own boxes are derived as the
+    unions of the grandchildren's (tests/test_fused_nodes.py).  Same visiting order, same stack contents, hence the same frames: single-leaf mesh (nothing to fuse),
+    one-level tree, depth-12 tree -- and a tree whose boxes are NOT the unions of their children's (one inner box inflated): rt_upload_bvh must refuse to fuse it
+    (RT_SCENE_NOT_FUSED) and the option must fall back to the 64-byte records.  Besides frames: the reference GLSL's own traversal answers for the `crate`
+    height field (552 rays with two or more triangles at the bit-equal winning t: the normal shows which one the visiting order left standing)."""
+    monkeypatch.setenv("RT_FUSED", "1")
+    W, H = 96, 64
+    if mesh == "one_leaf":
+        tris9 = np.array([[-1, 0, -1, 1, 0, -1, 0, 1.5, -1.2], [-1, 0, 1, 1, 0, 1, 0, 1.5, 0.5]], np.float32) + np.float32(0.25)
+        nodes, tris = rt.build_bvh(tris9)
+    else:
+        nodes, tris = scenes.bunny_bvh(0 if mesh == "tiny" else 4)
+    if inflate:
+        nodes = nodes.copy()
+        count = (nodes[:, 9] + 0.5).astype(int)
+        k = int(np.nonzero(count == 0)[0][5])
+        nodes[k, 0:3] -= np.float32(0.01)                # a legal, looser box: the reference (and the oracle) simply test it as it is
+    faces = scenes.tiny_env(8)
+    p = rt.default_render_params()
+    p.sppPerFrame = 2
+    cam = scenes.camera("closeup", aspect=W / H)
+    with rt.Renderer(pipeline=rt.RT_PIPELINE_WAVEFRONT) as r:
+        r.upload_bvh(nodes, tris)
+        info = r.scene_info()
+        if mesh == "one_leaf":
+            assert info.nFused == 0 and not (info.flags & rt.RT_SCENE_NOT_FUSED)
+        elif inflate:
+            assert info.nFused == 0 and (info.flags & rt.RT_SCENE_NOT_FUSED)
+        else:
+            assert info.nFused > 0 and not (info.flags & rt.RT_SCENE_NOT_FUSED)
+        r.upload_env(faces)
+        r.resize(W, H)
+        prev = None
+        for f in range(2):
+            u = rt.frame_uniforms(p, cam, W, H, f, True, nodes.shape[0], tris.shape[0])
+            r.render_frame(u)
+            want, _ = orc.render(u, nodes, tris, faces, prev)
+            _assert_targets_equal(r.read_all(), want, orc, f"RT_FUSED=1 {mesh} inflate={inflate} frame={f}")
+            prev = want[0]
+        if mesh == "deep" and not inflate:
+            from pathlib import Path
+            d = np.load(Path(__file__).resolve().parent / "golden" / "glsl_bvh_trace_kat.npz")
+            for tag in ("crate", "bunny"):
+                kn, kt, rays = d[f"{tag}_nodes12"], d[f"{tag}_tris12"], d[f"{tag}_rays"]
+                r.upload_bvh(kn, kt)
+                assert r.scene_info().nFused > 0
+                eps, inf = float(d["eps"]), float(d["inf"])
+                mega = r.debug_trace(0, rays[:, 0:3], rays[:, 4:7], eps=eps, inf=inf)     # the walk tests/test_gpu_glsl_reference.py pins to the reference GLSL's answers
+                fused = r.debug_trace(2, rays[:, 0:3], rays[:, 4:7], eps=eps, inf=inf)    # the production kernel on the fused records
+                assert np.array_equal(fused[:, 0].view(np.uint32), mega[:, 0].view(np.uint32)), tag
+                hit = mega[:, 0] < np.float32(inf)
+                tri = fused[hit, 1].astype(int)
+                nrm = np.cross(kt[tri, 4:7].astype(np.float64), kt[tri, 8:11].astype(np.float64))
+                nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+                assert np.all(np.abs(np.sum(nrm * mega[hit, 4:7].astype(np.float64), axis=1) - 1.0) < 1e-5), tag   # the same winner on every tie
+                assert hit.sum() >= 900
 
 
 @pytest.fixture(scope="module")
