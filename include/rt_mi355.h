@@ -288,12 +288,15 @@ int rt_reset_counters(RtContext *ctx);
  * 4 MB the any-hit launches walk its quantised form instead: bytesNodes4 is then 64 bytes per four-child record + 32
  * bytes of exact box per leaf. */
 #define RT_SCENE_QNODES_REJECTED 1   /* quantised any-hit nodes were asked for (tree size or RT_QNODES) but could not be built: the exact nodes are walked */
+#define RT_SCENE_IMPLICIT 4          /* every leaf sits at one depth: the traversal launches walk 48-byte records without child references */
 #define RT_SCENE_NOT_FUSED 2         /* some inner box is not the union of its children's: closest-hit rays walk the 64-byte records, not the fused ones */
 typedef struct RtSceneInfo {
     int32_t nNodes, nTris, nInner, treeDepth, nWide4, nPairs;
     uint64_t bytesNodes2, bytesNodes4, bytesPairs, bytesTris;
     int32_t nFused;   /* fused closest-hit records (128 B per even-level inner node; 0: not built), DESIGN.md 4.2 */
     int32_t flags;    /* RT_SCENE_* */
+    int32_t implicitDepth;   /* depth every leaf sits at when RT_SCENE_IMPLICIT is set */
+    int32_t reserved;
 } RtSceneInfo;
 int rt_get_scene_info(const RtContext *ctx, RtSceneInfo *out);
 

@@ -140,7 +140,7 @@ class RtTracedRays(_Struct):
 class RtSceneInfo(_Struct):
     _fields_ = [(n, i32) for n in ("nNodes", "nTris", "nInner", "treeDepth", "nWide4", "nPairs")] + \
                [(n, C.c_uint64) for n in ("bytesNodes2", "bytesNodes4", "bytesPairs", "bytesTris")] + \
-               [("nFused", i32), ("flags", i32)]
+               [("nFused", i32), ("flags", i32), ("implicitDepth", i32), ("reserved", i32)]
 
 
 class RtMemoryInfo(_Struct):
@@ -153,7 +153,7 @@ class RtExtension(_Struct):
 
 
 RT_SCENE_HYBRID = 2   # RtUniforms.useBVH: the analytic scene + the BVH mesh (extension, not in the reference)
-RT_SCENE_QNODES_REJECTED, RT_SCENE_NOT_FUSED = 1, 2   # RtSceneInfo.flags
+RT_SCENE_QNODES_REJECTED, RT_SCENE_NOT_FUSED, RT_SCENE_IMPLICIT = 1, 2, 4   # RtSceneInfo.flags
 
 
 class RtPresentParams(_Struct):  # uniforms of shaders/rt/rt_present.frag:38-50

@@ -45,6 +45,8 @@ struct RtContext {
     float4 *dWNodes = nullptr, *dW4 = nullptr, *dTris = nullptr, *dWNodesW = nullptr, *dPairs = nullptr;
     float4 *dQ4 = nullptr, *dLeafBox = nullptr;   // RT_QNODES: quantised any-hit nodes + the leaves' exact boxes
     float4 *dWF = nullptr;           // fused closest-hit records (round 5), null when the tree's boxes are not the unions of their children's
+    float4 *dIN2 = nullptr, *dIPairs = nullptr;   // implicit records (round 5): 48-byte two-child records without references + the pair records in leaf order; null unless every leaf sits at depth implD
+    int implD = 0, implR = 0;
     size_t nFused = 0;
     int sceneFlags = 0;              // RT_SCENE_* bits of RtSceneInfo.flags
     int rootRefW = 0;
@@ -227,6 +229,7 @@ DevScene make_dev_scene(const RtContext *c) {
     s.leafBoxMagic = c->leafBoxMagic;
     s.wnodesW = c->dWNodesW;
     s.wF = c->dWF;
+    s.iN2 = c->dIN2; s.iPairs = c->dIPairs; s.implD = c->implD; s.implR = c->implR;
     s.pairs = c->dPairs;
     s.rootRefW = c->rootRefW;
     s.tris = c->dTris;
@@ -406,6 +409,8 @@ void rt_destroy(RtContext *c) {
     if (c->dLeafBox) (void)hipFree(c->dLeafBox);
     if (c->dWNodesW) (void)hipFree(c->dWNodesW);
     if (c->dWF) (void)hipFree(c->dWF);
+    if (c->dIN2) (void)hipFree(c->dIN2);
+    if (c->dIPairs) (void)hipFree(c->dIPairs);
     if (c->dPairs) (void)hipFree(c->dPairs);
     if (c->dTris) (void)hipFree(c->dTris);
     if (c->dEnv) (void)hipFree(c->dEnv);
@@ -428,6 +433,9 @@ int rt_upload_bvh(RtContext *c, const float *nodes12, int nNodes, const float *t
     if (c->dLeafBox) (void)hipFree(c->dLeafBox);
     if (c->dWNodesW) (void)hipFree(c->dWNodesW);
     if (c->dWF) (void)hipFree(c->dWF);
+    if (c->dIN2) (void)hipFree(c->dIN2);
+    if (c->dIPairs) (void)hipFree(c->dIPairs);
+    c->dIN2 = c->dIPairs = nullptr; c->implD = c->implR = 0;
     if (c->dPairs) (void)hipFree(c->dPairs);
     if (c->dTris) (void)hipFree(c->dTris);
     c->dWNodes = c->dW4 = c->dTris = c->dWNodesW = c->dPairs = c->dQ4 = c->dLeafBox = c->dWF = nullptr;
@@ -863,12 +871,77 @@ int rt_upload_bvh(RtContext *c, const float *nodes12, int nNodes, const float *t
         }
         if (!okF) { wF.clear(); if (nd[0].count <= 0) c->sceneFlags |= RT_SCENE_NOT_FUSED; }
     }
+    // Round 5 -- implicit records.  What the traversal launches cost is their 16-byte lane-loads (one vector-L1 lookup each), and a 64-byte
+    // two-child record spends one of its four on two child references.  The reference's builder splits every range at its middle and stops at <= 8 triangles
+    // (bvh.cpp:62-76), so whenever n / 2^D falls into [4.5, 8] for some D every leaf sits at depth D and the tree is a perfect binary tree: a node is named by
+    // (depth d, path p = the left / right turns from the root as a binary number), its children are (d + 1, 2p) and (d + 1, 2p + 1), the leaves are p = 0 ..
+    // 2^D - 1 at depth D -- no reference needs to be stored.  Records: 48 bytes = the two child boxes = THREE loads, at the node's pre-order position
+    // d - popcount(p) + (p << (D - d)) (a left child sits next to its parent, as in the reference's own numbering); a leaf's triangle-pair records at
+    // p * R (R = the most records any leaf owns), the leaf's triangle count in the spare word of its first record.  Visiting order, boxes and triangle tests
+    // are those of the 64-byte records.  Checked here for whatever tree was uploaded (all leaves at one depth <= 23); others keep the explicit records.
+    std::vector<float> iN2, iPairs;
+    int implD = 0, implR = 0;
+    if (nd[0].count <= 0 && !(getenv("RT_IMPLICIT_BUILD") && atoi(getenv("RT_IMPLICIT_BUILD")) == 0)) {
+        struct E { int node; int d; uint32_t p; };
+        std::vector<E> st{{0, 0, 0u}};
+        std::vector<int> nodeD((size_t)nNodes, -1);
+        std::vector<uint32_t> nodeP((size_t)nNodes, 0u);
+        int leafDepth = -1, maxRec = 0;
+        bool uniform = true;
+        while (!st.empty() && uniform) {
+            const E e = st.back();
+            st.pop_back();
+            nodeD[(size_t)e.node] = e.d; nodeP[(size_t)e.node] = e.p;
+            const N &n = nd[(size_t)e.node];
+            if (n.count > 0) {
+                if (leafDepth < 0) leafDepth = e.d;
+                if (e.d != leafDepth) uniform = false;
+                maxRec = std::max(maxRec, (n.count + 1) / 2);
+            } else {
+                if (e.d >= 23) { uniform = false; break; }
+                st.push_back({n.left, e.d + 1, e.p * 2u});
+                st.push_back({n.right, e.d + 1, e.p * 2u + 1u});
+            }
+        }
+        if (uniform && leafDepth >= 1) {
+            const int D = leafDepth;
+            iN2.assign((((size_t)1 << D) - 1) * 12, 0.0f);
+            iPairs.assign((((size_t)1 << D) * (size_t)maxRec + 8) * 20, 0.0f);
+            for (int i = 0; i < nNodes; ++i) {
+                if (nodeD[(size_t)i] < 0) continue;             // (unreachable nodes: none in a valid tree)
+                const N &n = nd[(size_t)i];
+                const int d = nodeD[(size_t)i];
+                const uint32_t pth = nodeP[(size_t)i];
+                if (n.count <= 0) {
+                    const size_t at = (size_t)d - (size_t)__builtin_popcount(pth) + ((size_t)pth << (D - d));
+                    const float *L = nodes12 + (size_t)n.left * 12, *R = nodes12 + (size_t)n.right * 12;
+                    const float rec[12] = {L[0], L[1], L[2], L[4], L[5], L[6], R[0], R[1], R[2], R[4], R[5], R[6]};
+                    std::memcpy(&iN2[at * 12], rec, sizeof rec);
+                } else {
+                    // the leaf's records as `pairs` holds them, at p * R; the count in the spare word of the first
+                    const size_t src = (size_t)(-pairRefOf[(size_t)i] - 1) >> 3, nrec = (size_t)(n.count + 1) / 2;
+                    float *o = &iPairs[(size_t)pth * (size_t)maxRec * 20];
+                    std::memcpy(o, &pairs[src * 20], nrec * 20 * sizeof(float));
+                    const uint32_t cnt = (uint32_t)n.count;
+                    std::memcpy(&o[19], &cnt, 4);
+                }
+            }
+            implD = D; implR = maxRec;
+        }
+    }
     if (depth > 32) return fail(c, RT_ERR_UNSUPPORTED, "rt_upload_bvh: tree depth %d exceeds the 32-entry traversal stack", depth);
     if (!q4.empty()) {
         HIP_TRY(c, hipMalloc(&c->dQ4, q4.size() * 4));
         HIP_TRY(c, hipMemcpy(c->dQ4, q4.data(), q4.size() * 4, hipMemcpyHostToDevice));
         HIP_TRY(c, hipMalloc(&c->dLeafBox, leafBox.size() * 4));
         HIP_TRY(c, hipMemcpy(c->dLeafBox, leafBox.data(), leafBox.size() * 4, hipMemcpyHostToDevice));
+    }
+    if (!iN2.empty()) {
+        HIP_TRY(c, hipMalloc(&c->dIN2, iN2.size() * sizeof(float)));
+        HIP_TRY(c, hipMemcpy(c->dIN2, iN2.data(), iN2.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMalloc(&c->dIPairs, iPairs.size() * sizeof(float)));
+        HIP_TRY(c, hipMemcpy(c->dIPairs, iPairs.data(), iPairs.size() * sizeof(float), hipMemcpyHostToDevice));
+        c->implD = implD; c->implR = implR;
     }
     if (!wF.empty()) {
         HIP_TRY(c, hipMalloc(&c->dWF, wF.size() * sizeof(float)));
@@ -1319,7 +1392,8 @@ int rt_get_scene_info(const RtContext *c, RtSceneInfo *out) {
     out->bytesPairs = (uint64_t)c->nPairs * 80;
     out->bytesTris = (uint64_t)c->nTris * 48;
     out->nFused = (int32_t)c->nFused;
-    out->flags = c->sceneFlags;
+    out->flags = c->sceneFlags | (c->dIN2 ? RT_SCENE_IMPLICIT : 0);
+    out->implicitDepth = c->implD;
     return RT_OK;
 }
 

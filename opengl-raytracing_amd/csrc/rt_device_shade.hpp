@@ -34,6 +34,9 @@ struct DevScene {
     uint32_t leafBoxMagic;   // ceil(2^32 / R), R = fewest pair records of a leaf (0: index = first pair record), see rt_upload_bvh
     const float4 *wnodesW;   // wnodes with pair-record leaf references (wavefront closest-hit kernels)
     const float4 *wF;        // fused closest-hit records (round 5): 8 x float4 per even-level inner node = the wnodesW records of its two children, see rt_upload_bvh (null: not built)
+    const float4 *iN2;       // implicit two-child records (round 5): 3 x float4 per inner node [Lmin.xyz Lmax.x][Lmax.yz Rmin.xy][Rmin.z Rmax.xyz] at d - popcount(p) + (p << (implD - d)); null unless every leaf sits at depth implD
+    const float4 *iPairs;    // `pairs` in leaf order: leaf p owns the records from p * implR on, the spare word of the first holds the leaf's triangle count
+    int implD, implR;
     const float4 *pairs;     // 5 x float4 per PAIR of triangles of a leaf: [v0 e1 e2][v0 e1 e2][index of the first][-], see rt_upload_bvh
     const float4 *tris;
     const uchar4 *env;

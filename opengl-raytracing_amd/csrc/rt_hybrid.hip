@@ -39,7 +39,8 @@ enum { ST_TRACE_GI = 6, ST_RESOLVE = 8, ST_COMBINE = 9 };   // stage ids shared 
 // counters, at [k * kCnt]
 enum { C_OPEN = 0,      // threads that recorded in the shading pass just run (= entries of recd)
        C_REC = 1,       // queries recorded in it (= entries of the dense queue; keeps counting past the capacity)
-       C_FLAGS = 2,     // 1: a sample needs more than qmax queries, 2: dense queue too small, 4: log arena too small
+       C_FLAGS = 2,     // 1: a sample needs more than qmax queries, 2: dense queue too small, 4: log arena too small; RT_HYBRID_CHECK=1: 8 thread list,
+                        // 16 dense queue, 32 log arena, 64 staging area -- a store whose index lies outside the array it was given (never seen; see hb_ok)
        C_TODO = 3,      // entries of todo (threads the next pass shades again)
        C_LOG = 4,       // bump pointer of the log arena (entries; never reset inside a chunk; keeps counting past the capacity)
        C_MAXREC = 5,    // largest C_REC of any pass of the chunk (what the dense queue has to hold)
@@ -74,7 +75,17 @@ struct HybridBuf {
     uint32_t *cnt;
     uint32_t slot0, nS, T, qmax, capQ, capL;
     int SPP;
+    int check;             // RT_HYBRID_CHECK=1: every staged-record, thread-list, queue and log store compares its index with the capacity of its array first
 };
+
+// RT_HYBRID_CHECK=1 (diagnostic): the capacities of the dense queue and the log arena are ESTIMATES, and a pass that outgrows them is
+// supposed to count only (C_FLAGS 2 / 4) and store nothing.  With the check on, every store of the staged pipeline first proves that: an index at or beyond
+// the capacity its array was allocated with raises `bit` in C_FLAGS and the store is skipped; the host then ends the frame with RT_ERR_STATE.
+RT_DEV bool hb_ok(const HybridBuf &hb, uint32_t idx, uint32_t cap, uint32_t bit) {
+    if (!hb.check || idx < cap) return true;
+    atomicOr(&hb.cnt[C_FLAGS * kCnt], bit);
+    return false;
+}
 
 RT_DEV uint32_t wave_excl_scan(uint32_t v, uint32_t lane, uint32_t &total) {
     uint32_t incl = v;
@@ -208,10 +219,12 @@ __global__ __launch_bounds__(256, WAVES) void k_hybrid_shade(const DevFrame *__r
             const unsigned long long lt = (1ull << lane) - 1ull;
             const uint32_t newLog = lbase + lofs;
             if (open) {
-                hb.recd[tbase + (uint32_t)__popcll(om & lt)] = tid;      // whose speculation the next pass checks
+                const uint32_t rpos = tbase + (uint32_t)__popcll(om & lt);
+                if (hb_ok(hb, rpos, hb.T, 8u)) hb.recd[rpos] = tid;      // whose speculation the next pass checks
                 if (known) {
                     const uint32_t old = hb.logBase[tid];
-                    for (uint32_t q = 0; q < known; ++q) { hb.logT[newLog + q] = hb.logT[old + q]; hb.logTri[newLog + q] = hb.logTri[old + q]; }
+                    for (uint32_t q = 0; q < known; ++q)
+                        if (hb_ok(hb, newLog + q, hb.capL, 32u) && hb_ok(hb, old + q, hb.capL, 32u)) { hb.logT[newLog + q] = hb.logT[old + q]; hb.logTri[newLog + q] = hb.logTri[old + q]; }
                 }
                 hb.logBase[tid] = newLog;
             }
@@ -220,10 +233,12 @@ __global__ __launch_bounds__(256, WAVES) void k_hybrid_shade(const DevFrame *__r
                 if (recorded > k) {
                     const uint32_t pos = qbase + (uint32_t)__popcll(m & lt);
                     const size_t src = (size_t)(known + k) * 256u + threadIdx.x;
-                    const float4 oo = stgO[src], dd = stgD[src];
                     const uint32_t a = newLog + known + k;
-                    hb.qO[pos] = oo; hb.qD[pos] = dd; hb.qDst[pos] = a;
-                    hb.logLim[a] = dd.w != 0.0f ? -oo.w : oo.w;
+                    if (hb_ok(hb, known + k, hb.qmax, 64u) && hb_ok(hb, pos, hb.capQ, 16u) && hb_ok(hb, a, hb.capL, 32u)) {
+                        const float4 oo = stgO[src], dd = stgD[src];
+                        hb.qO[pos] = oo; hb.qD[pos] = dd; hb.qDst[pos] = a;
+                        hb.logLim[a] = dd.w != 0.0f ? -oo.w : oo.w;
+                    }
                 }
                 qbase += (uint32_t)__popcll(m);
             }
@@ -255,6 +270,7 @@ __global__ __launch_bounds__(256) void k_hybrid_verify(HybridBuf hb) {
         uint32_t tid = 0;
         if (j < n) {
             tid = hb.recd[j];
+            if (!hb_ok(hb, tid, hb.T, 8u)) tid = 0u;
             const uint32_t st = hb.state[tid];
             const uint32_t kn = st & 0xffffu, rec = st >> 16;
             const uint32_t base = hb.logBase[tid];
@@ -262,6 +278,7 @@ __global__ __launch_bounds__(256) void k_hybrid_verify(HybridBuf hb) {
             uint32_t valid = rec;                      // answers [kn, valid) are answers to queries the true frame asks
             for (uint32_t q = kn; q < rec; ++q) {
                 const uint32_t a = base + q;
+                if (!hb_ok(hb, a, hb.capL, 32u)) break;
                 const float lim = hb.logLim[a];
                 if (hb.logTri[a] >= 0 && hb.logT[a] < __builtin_fabsf(lim)) {   // a mesh hit in front of the analytic scene's: the speculation failed here
                     anyHit = true;
@@ -282,7 +299,8 @@ __global__ __launch_bounds__(256) void k_hybrid_verify(HybridBuf hb) {
         if (again) {
             uint32_t base = sBase;
             for (uint32_t k = 0; k < wv; ++k) base += sAgain[k];
-            hb.todo[base + (uint32_t)__popcll(am & ((1ull << lane) - 1ull))] = tid;
+            const uint32_t tpos = base + (uint32_t)__popcll(am & ((1ull << lane) - 1ull));
+            if (hb_ok(hb, tpos, hb.T, 8u)) hb.todo[tpos] = tid;
         }
         __syncthreads();
     }
@@ -339,6 +357,8 @@ struct RtHybrid {
     uint32_t *hostCnt = nullptr;       // pinned
     unsigned long long passes = 0, launches = 0, redone = 0;
     bool debug = false;                // RT_HYBRID_DEBUG=1: per-pass counts on stderr (one host round trip per pass)
+    bool check = false;                // RT_HYBRID_CHECK=1: bounds-checked stores (hb_ok)
+    size_t okSlots = 0;                // largest chunk of pixel slots the arena could be allocated for after an out-of-memory answer (0: none seen); later chunks and frames start from it
 };
 
 RtHybrid *rt_hybrid_create(int cus) {
@@ -349,6 +369,7 @@ RtHybrid *rt_hybrid_create(int cus) {
     if (const char *e = getenv("RT_HYBRID_RATIO_L")) h->ratioL = std::max(0.001, atof(e));
     (void)hipEventCreateWithFlags(&h->evFree, hipEventDisableTiming);
     if (const char *e = getenv("RT_HYBRID_DEBUG")) h->debug = atoi(e) != 0;
+    if (const char *e = getenv("RT_HYBRID_CHECK")) h->check = atoi(e) != 0;
     return h;
 }
 void rt_hybrid_destroy(RtHybrid *h) {
@@ -421,6 +442,7 @@ int rt_hybrid_render(RtHybrid *h, RtContext *ctx, hipStream_t st, const DevFrame
         // chunk of pixel slots from the budget, at the current capacity estimates
         const double perSlot = (double)SPP * (32.0 + h->ratioQ * 36.0 + h->ratioL * 12.0) + 40.0;
         size_t nS = std::min(nSlots - slot0, std::max<size_t>((size_t)((double)h->budgetBytes / perSlot), 256));
+        if (h->okSlots) nS = std::min(nS, h->okSlots);      // what the device could give last time it refused the budget-sized arena
         nS = std::max<size_t>(nS / 256 * 256, 256);
         nS = std::min(nS, nSlots - slot0);      // nSlots is a multiple of 256
         size_t T = nS * (size_t)SPP;
@@ -432,6 +454,7 @@ int rt_hybrid_render(RtHybrid *h, RtContext *ctx, hipStream_t st, const DevFrame
         if (h->arenaBytes < need) {
             // the arena grows on demand; when the device cannot give that much (other contexts, the wavefront pipeline's arenas), the chunk is halved
             // until it fits -- the chunked path is the tested one
+            // (freeing after a sync of `st` alone is enough: `st` has waited on evFree above, i.e. on the last kernel any OTHER lane's stream ran on this arena)
             if (h->arena) { H_TRY(hipStreamSynchronize(st)); (void)hipFree(h->arena); }
             h->arena = nullptr; h->arenaBytes = 0;
             for (;;) {
@@ -441,6 +464,7 @@ int rt_hybrid_render(RtHybrid *h, RtContext *ctx, hipStream_t st, const DevFrame
                 h->arena = nullptr;
                 if (e != hipErrorOutOfMemory || nS <= 256) { h->err = std::string("hybrid arena: hipMalloc(") + std::to_string(need) + "): " + hipGetErrorString(e); return RT_ERR_HIP; }
                 nS = std::max<size_t>(nS / 2 / 256 * 256, 256);
+                h->okSlots = nS;                // remembered: the next chunk and the next frame start here instead of failing the same allocations again
                 T = nS * (size_t)SPP;
                 capQ = std::min(std::max<size_t>((size_t)((double)T * h->ratioQ) + 4096, 4096), T * (size_t)qmax);
                 capL = std::min<size_t>(std::min(std::max<size_t>((size_t)((double)T * h->ratioL) + 4096, 4096), T * (size_t)qmax * 4), 0xfffffff0u);
@@ -459,7 +483,7 @@ int rt_hybrid_render(RtHybrid *h, RtContext *ctx, hipStream_t st, const DevFrame
             hb.sMotion = (float2 *)take(nS * 8); hb.sPos = (float4 *)take(nS * 16); hb.sNrm = (float4 *)take(nS * 16);
             hb.stgO = (float4 *)h->staging; hb.stgD = (float4 *)((char *)h->staging + stgEach);
         }
-        hb.cnt = h->cnt; hb.qmax = qmax; hb.SPP = SPP;
+        hb.cnt = h->cnt; hb.qmax = qmax; hb.SPP = SPP; hb.check = h->check ? 1 : 0;
         hb.capQ = (uint32_t)std::min<size_t>(capQ, 0xfffffff0u); hb.capL = (uint32_t)capL;
         hb.slot0 = (uint32_t)slot0; hb.nS = (uint32_t)nS; hb.T = (uint32_t)T;
 
@@ -482,7 +506,7 @@ int rt_hybrid_render(RtHybrid *h, RtContext *ctx, hipStream_t st, const DevFrame
                 rt_stage_end(ctx, ST_COMBINE, 2, st);
                 H_TRY(hipMemsetAsync(h->heads, 0, rt_wave_head_words() * sizeof(uint32_t), st));
                 rt_stage_begin(ctx, ST_TRACE_GI, st);
-                rt_wave_trace_closest_compact(st, h->cus, treeDepth, dFrame, host.sc, hb.qO, hb.qD, hb.qDst, &h->cnt[C_REC * kCnt], &h->cnt[C_FLAGS * kCnt], hb.capQ, hb.logT, hb.logTri, h->heads);
+                rt_wave_trace_closest_compact(st, h->cus, treeDepth, dFrame, host.sc, hb.qO, hb.qD, hb.qDst, &h->cnt[C_REC * kCnt], &h->cnt[C_FLAGS * kCnt], hb.capQ, hb.logT, hb.logTri, h->heads, h->check ? hb.capL : 0u);
                 rt_stage_end(ctx, ST_TRACE_GI, 1, st);
                 h->launches++;
                 // the threads that recorded check their speculation; who failed is packed into the next pass's list
@@ -501,6 +525,7 @@ int rt_hybrid_render(RtHybrid *h, RtContext *ctx, hipStream_t st, const DevFrame
             H_TRY(hipStreamSynchronize(st));
             const uint32_t flags = h->hostCnt[C_FLAGS * kCnt];
             if (flags & 1u) { h->err = "hybrid: a sample needs more than " + std::to_string(qmax) + " mesh queries"; return RT_ERR_UNSUPPORTED; }
+            if (flags & 0x78u) { h->err = "hybrid check (RT_HYBRID_CHECK): a store left its array, flags " + std::to_string(flags) + " (8 thread list, 16 queue, 32 log, 64 staging)"; return RT_ERR_STATE; }
             if (flags & 6u) {
                 // a pass outgrew the queue or the log arena: it wrote nothing, what follows it is void.  Enlarge from what was asked for and render the chunk again.
                 if (flags & 2u) h->ratioQ = std::max(h->ratioQ * 1.5, (double)h->hostCnt[C_MAXREC * kCnt] / (double)T * 1.25);

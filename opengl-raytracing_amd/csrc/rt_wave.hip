@@ -378,6 +378,7 @@ struct CompactSrc {
     const uint32_t *count;
     const uint32_t *flags;   // bits 2 | 4: a pass outgrew its arrays -- the queue is incomplete and must not be traced
     uint32_t cap;
+    uint32_t capOut;         // RT_HYBRID_CHECK=1: entries of outT / outTri; an answer addressed beyond them raises bit 32 of *flags instead of being stored (0: unchecked)
     float *outT;
     int *outTri;
     uint32_t n;
@@ -391,7 +392,10 @@ struct CompactSrc {
         const float4 oo = o[p.a], dd = d[p.a];
         ro = f4xyz(oo); rd = f4xyz(dd);
     }
-    RT_DEV void store_closest(uint32_t a, float t, int tri) const { outT[a] = t; outTri[a] = tri; }
+    RT_DEV void store_closest(uint32_t a, float t, int tri) const {
+        if (capOut && a >= capOut) { atomicOr(const_cast<uint32_t *>(flags), 32u); return; }
+        outT[a] = t; outTri[a] = tri;
+    }
     RT_DEV void store_any(uint32_t, bool) const {}
     RT_DEV bool dense(uint32_t, uint32_t) const { return false; }
     RT_DEV float probe_take(uint32_t, V3 &, V3 &, uint32_t &) const { return -1.0f; }
@@ -481,13 +485,18 @@ RT_DEV uint32_t quad_distinct(uint32_t key) {
 constexpr uint32_t kShards = 64, kShardStride = 32;   // cursor shards per trace launch, uint32 words between them (128 B)
 constexpr uint32_t kHeadWords = kShards * kShardStride;
 
-struct TraceTune { int refillMin; int minSearch; int chunk; int leafb; int skipTraversal; int quadRefill; int coop; int leafbClosest; int nearFirst; int reverse; int guided; int chunkMax; int denseTake; int qnodes; int fused; };   // skipTraversal: diagnostic (RT_DEBUG_SKIP_TRAVERSAL)
+struct TraceTune { int refillMin; int minSearch; int chunk; int leafb; int skipTraversal; int quadRefill; int coop; int leafbClosest; int nearFirst; int reverse; int guided; int chunkMax; int denseTake; int qnodes; int fused; int impl; };   // skipTraversal: diagnostic (RT_DEBUG_SKIP_TRAVERSAL)
 // fused (RT_FUSED=1, measured option of round 5, off): closest-hit launches walk the fused records (DevScene::wF) when rt_upload_bvh built them -- the reference's
 // visiting order in half the dependent round trips (bounce rays: 20.6 -> 11.2 steps, primary 17.1 -> 9.7), bit-identical, and 3-4 % SLOWER in every mode (batched,
 // frame by frame, one rank of eight): the same number of 16-byte lane-loads per ray, and that number -- not the length of the dependency chain -- is what these
 // launches cost (profiles/r05_experiments.txt 1)
 static TraceTune default_tune() {
-    TraceTune t{32, 16, 0, 2, 0, 0, 0, 2, 0, 1, 0, 768, 1, -1, 0};
+    TraceTune t{32, 16, 0, 2, 0, 0, 0, 2, 0, 1, 0, 768, 1, -1, 0, 0};
+    // impl (RT_IMPLICIT=1, measured option of round 5, off): closest-hit launches walk 48-byte records WITHOUT child references (three loads per node visit instead of
+    // four) when every leaf of the tree sits at one depth (rt_upload_bvh) -- bit-identical, 25 % fewer node loads, and no faster (bounce launch 0.615 -> 0.628 ms per
+    // frame, primary 0.253 -> 0.259): together with `fused` the second half of the finding that neither the loads nor the dependent steps of these launches can be
+    // removed for time while their vector instructions stay (profiles/r05_experiments.txt 2)
+    if (const char *e = getenv("RT_IMPLICIT")) t.impl = atoi(e);
     if (const char *e = getenv("RT_FUSED")) t.fused = atoi(e);
     return t;
 }
@@ -529,7 +538,7 @@ extern __shared__ __align__(16) unsigned char rt_dyn_lds[];
 #ifndef RT_ANYHIT_WAVES
 #define RT_ANYHIT_WAVES 7   // any-hit launches: 72 VGPRs, seven waves per SIMD (with the exact stack size of rt_upload_bvh seven workgroups fit a CU's LDS)
 #endif
-template <class Src, bool ANY, int LEAFB, bool STATS = false, bool COOP = false, bool NEAR = false, int QN = 0, bool FUSE = false>
+template <class Src, bool ANY, int LEAFB, bool STATS = false, bool COOP = false, bool NEAR = false, int QN = 0, bool FUSE = false, bool IMPL = false>
 __global__ __launch_bounds__(256, (!STATS && !ANY) ? 5 : ((NEAR || QN == 2) ? 6 : (ANY && !STATS && LEAFB == 2 ? RT_ANYHIT_WAVES : 1))) void k_trace(const DevFrame *__restrict__ fr, const float4 *__restrict__ wnodes, const float4 *__restrict__ tris, Src src,
                                                 uint32_t *head, unsigned long long *tally, unsigned long long *gatherLoads, TraceTune tune,
                                                 int stackEntries, unsigned long long *stats = nullptr, const float4 *__restrict__ leafBox = nullptr) {
@@ -757,7 +766,7 @@ __global__ __launch_bounds__(256, (!STATS && !ANY) ? 5 : ((NEAR || QN == 2) ? 6 
                 quad_transpose(ca, cb, cc, cd);
             }
             if (searching) {
-                if (STATS) { st_[0]++; const uint32_t dk = quad_distinct((uint32_t)ref), dw = wave_distinct((uint32_t)ref); if (lane == (uint32_t)(__ffsll((long long)sm) - 1)) { st_[12] += dk * (ANY ? 7u : 4u); st_[14] += dw * (ANY ? 7u : 4u); } }
+                if (STATS) { st_[0]++; const uint32_t dk = quad_distinct((uint32_t)ref), dw = wave_distinct((uint32_t)ref); if (lane == (uint32_t)(__ffsll((long long)sm) - 1)) { st_[12] += dk * (ANY ? 7u : (IMPL ? 3u : 4u)); st_[14] += dw * (ANY ? 7u : (IMPL ? 3u : 4u)); } }
                 gathers += ANY ? (QN ? 4u : 7u) : 4u;
                 if constexpr (ANY) {
                     int r0, r1, r2, r3;
@@ -828,6 +837,33 @@ __global__ __launch_bounds__(256, (!STATS && !ANY) ? 5 : ((NEAR || QN == 2) ? 6 
                     take(h0, r0); take(h1, r1); take(h2, r2); take(h3, r3);
                     if (nxt == RT_NO_CHILD) pop_or_finish();
                     else ref = nxt;
+                } else if constexpr (IMPL) {
+                    // Implicit records (round 5, rt_upload_bvh): every leaf at depth D, so a node is (depth d, path p), `ref` = d << 24 | p, its children (d + 1, 2p)
+                    // and (d + 1, 2p + 1), a leaf the reference -(p + 1); the record -- the two child boxes, 48 bytes, THREE loads instead of four -- sits at the
+                    // node's pre-order position.  Boxes, tests, order and stack contents are those of the 64-byte records below.
+                    const uint32_t dN = (uint32_t)ref >> 24, pN = (uint32_t)ref & 0x00ffffffu;
+                    const uint32_t at = dN - (uint32_t)__popc(pN) + (pN << ((uint32_t)sc.implD - dN));
+                    const v4f *ndv = reinterpret_cast<const v4f *>(nodes) + (size_t)at * 3;
+                    v4f a = ndv[0], b = ndv[1], c = ndv[2];
+                    pin(a); pin(b); pin(c);
+                    gathers -= 1u;                                              // (4 were counted above)
+                    float tL, tR;
+                    const bool hitL = slab(ro, rdInv, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), tL) && tL <= tBest;
+                    const bool hitR = slab(ro, rdInv, mk3(b.z, b.w, c.x), mk3(c.y, c.z, c.w), tR) && tR <= tBest;
+                    const bool lastLevel = dN + 1u == (uint32_t)sc.implD;
+                    const int refL = lastLevel ? -(int)(2u * pN + 1u) : (int)(((dN + 1u) << 24) | (2u * pN));
+                    const int refR = lastLevel ? -(int)(2u * pN + 2u) : (int)(((dN + 1u) << 24) | (2u * pN + 1u));
+                    if (hitL && hitR) {
+                        const bool leftFirst = tL < tR;
+                        StackEntry e;
+                        e.x = (uint32_t)(leftFirst ? refR : refL);
+                        e.y = f2u(leftFirst ? tR : tL);
+                        stk[sp * 64] = e;
+                        sp++;
+                        ref = leftFirst ? refL : refR;
+                    } else if (hitL || hitR) {
+                        ref = hitL ? refL : refR;
+                    } else pop_or_finish();
                 } else if constexpr (FUSE) {
                     // Fused records (round 5, rt_upload_bvh): `ref` names a hub N -- an even-level inner node whose 128-byte record holds the 64-byte records of its
                     // two children A and B -- or, with kPair set, ONE of those children (a far child the step at N deferred).  A full step is the reference's step
@@ -918,6 +954,7 @@ __global__ __launch_bounds__(256, (!STATS && !ANY) ? 5 : ((NEAR || QN == 2) ? 6 
             if (STATS) st_[1]++;
             int v = -leafNow - 1;
             int first = v >> 3, count = (v & 7) + 1;   // first: pair record, count: triangles
+            if constexpr (IMPL) { first = v * sc.implR; count = 2; }   // implicit records: leaf v owns the records from v * R on; its count arrives with the first of them (below)
             bool done = false;
             // RT_QNODES: the leaf's exact box (the test the 112-byte node makes in the parent) -- fetched together with the first triangle group, tested after it
             bool boxOK = true;
@@ -969,6 +1006,26 @@ __global__ __launch_bounds__(256, (!STATS && !ANY) ? 5 : ((NEAR || QN == 2) ? 6 
                 }
             };
             int i = 0;
+            if constexpr (IMPL) {
+                // first record of the leaf: one or two triangles and, in its spare word, the leaf's triangle count
+                const v4f *tv = reinterpret_cast<const v4f *>(sc.tris + (size_t)first * 5);
+                gathers += 5u;
+                v4f r0 = tv[0], r1 = tv[1], r2 = tv[2], r3 = tv[3], r4 = tv[4];
+                pin(r0); pin(r1); pin(r2); pin(r3); pin(r4);
+                count = (int)f2u(r4.w);
+                if (STATS) st_[2] += (unsigned long long)min(count, 2);
+                float tt;
+                if (tri_hit(ro, rd, mk3(r0.x, r0.y, r0.z), mk3(r0.w, r1.x, r1.y), mk3(r1.z, r1.w, r2.x), eps, tBest, tt)) {
+                    if (ANY) done = true;
+                    else { tBest = tt; triBest = (int)f2u(r4.z); }
+                }
+                if (!done && count >= 2 && tri_hit(ro, rd, mk3(r2.y, r2.z, r2.w), mk3(r3.x, r3.y, r3.z), mk3(r3.w, r4.x, r4.y), eps, tBest, tt)) {
+                    if (ANY) done = true;
+                    else { tBest = tt; triBest = (int)f2u(r4.z) + 1; }
+                }
+                i = 2;
+                if (count == 1) count = 2;                 // (nothing left: keeps the odd-tail test below from firing for a one-triangle leaf)
+            }
             if constexpr (LEAFB >= 4) for (; i + 4 <= count && !done; i += 4) group(std::integral_constant<int, 2>{}, i);
             for (; i + 2 <= count && !done && boxOK; i += 2) group(std::integral_constant<int, 1>{}, i);
             // ... then the odd last triangle of the leaf: its record holds ONE triangle, whose nine floats (and, for closest-hit rays, its
@@ -1513,7 +1570,9 @@ void launch_trace(hipStream_t st, int cus, int gridPct, int depth, const DevFram
     const size_t ldsBytes = (size_t)256 * stack * (ANY ? 4 : 8);
     const bool qn = ANY && tune.qnodes != 0 && hs.q4 != nullptr && !stats && !tune.nearFirst;   // (the diagnostic and near-first builds walk the exact nodes)   // -1: whenever rt_upload_bvh built the quantised nodes (trees beyond the L2)
     const bool fuse = !ANY && tune.fused != 0 && hs.wF != nullptr && !tune.coop;   // closest-hit launches: the fused records when rt_upload_bvh built them
-    const float4 *nodes = ANY ? (qn ? hs.q4 : hs.w4) : (fuse ? hs.wF : hs.wnodesW);
+    const bool impl = !ANY && !fuse && tune.impl != 0 && hs.iN2 != nullptr && !tune.coop;   // ... the implicit records when every leaf sits at one depth
+    const float4 *nodes = ANY ? (qn ? hs.q4 : hs.w4) : (fuse ? hs.wF : (impl ? hs.iN2 : hs.wnodesW));
+    const float4 *pairRecords = impl ? hs.iPairs : hs.pairs;
     auto go = [&](auto kernel) {
         // the runtime's answer per (device, kernel, LDS bytes): a process may hold contexts on devices of different shapes
         thread_local std::map<std::tuple<int, const void *, size_t>, int> occ;
@@ -1525,10 +1584,12 @@ void launch_trace(hipStream_t st, int cus, int gridPct, int depth, const DevFram
             perCU = std::min(perCU, 8);
         }
         const unsigned blocks = (unsigned)std::max(8, cus * perCU * gridPct / 100);
-        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), ldsBytes, st, fr, nodes, hs.pairs, src, head, tally, gatherLoads, tune, stack, stats, hs.leafBox);
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), ldsBytes, st, fr, nodes, pairRecords, src, head, tally, gatherLoads, tune, stack, stats, hs.leafBox);
     };
     const int leafb = ANY ? tune.leafb : tune.leafbClosest;
-    if (stats && fuse) go(k_trace<Src, ANY, 2, true, false, false, 0, !ANY>);
+    if (stats && impl) go(k_trace<Src, ANY, 2, true, false, false, 0, false, !ANY>);
+    else if (impl) go(k_trace<Src, ANY, 2, false, false, false, 0, false, !ANY>);
+    else if (stats && fuse) go(k_trace<Src, ANY, 2, true, false, false, 0, !ANY>);
     else if (stats) { if (leafb >= 4) go(k_trace<Src, ANY, 4, true>); else go(k_trace<Src, ANY, 2, true>); }
     else if (fuse) go(k_trace<Src, ANY, 2, false, false, false, 0, !ANY>);
     else if (!ANY && tune.coop) go(k_trace<Src, ANY, 2, false, !ANY>);
@@ -1951,9 +2012,9 @@ void rt_wave_trace_closest_indexed(hipStream_t st, int cus, int treeDepth, const
     launch_trace<IndexedSrc, false>(st, cus, 100, treeDepth, dFrame, hostScene, q, heads, nullptr, nullptr, tune, nullptr);
 }
 void rt_wave_trace_closest_compact(hipStream_t st, int cus, int treeDepth, const DevFrame *dFrame, const DevScene &hostScene, const float4 *o, const float4 *d,
-                                   const uint32_t *dst, const uint32_t *count, const uint32_t *flags, uint32_t cap, float *outT, int *outTri, uint32_t *heads) {
+                                   const uint32_t *dst, const uint32_t *count, const uint32_t *flags, uint32_t cap, float *outT, int *outTri, uint32_t *heads, uint32_t capOut) {
     CompactSrc q;
-    q.o = o; q.d = d; q.dst = dst; q.count = count; q.flags = flags; q.cap = cap; q.outT = outT; q.outTri = outTri; q.n = 0;
+    q.o = o; q.d = d; q.dst = dst; q.count = count; q.flags = flags; q.cap = cap; q.capOut = capOut; q.outT = outT; q.outTri = outTri; q.n = 0;
     TraceTune tune = default_tune();
     launch_trace<CompactSrc, false>(st, cus, 100, treeDepth, dFrame, hostScene, q, heads, nullptr, nullptr, tune, nullptr);
 }

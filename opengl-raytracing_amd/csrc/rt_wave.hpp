@@ -40,7 +40,8 @@ void rt_wave_trace_closest_indexed(hipStream_t st, int cus, int treeDepth, const
 // The same over a dense array of records o[r] / d[r], r < min(*count, cap); the answer of record r goes to outT / outTri at dst[r].
 // Nothing is traced when *flags has bit 2 or 4 set (rt_hybrid.hip: a pass that outgrew its arrays left the queue incomplete).
 void rt_wave_trace_closest_compact(hipStream_t st, int cus, int treeDepth, const rtd::DevFrame *dFrame, const rtd::DevScene &hostScene, const float4 *o, const float4 *d,
-                                   const uint32_t *dst, const uint32_t *count, const uint32_t *flags, uint32_t cap, float *outT, int *outTri, uint32_t *heads);
+                                   const uint32_t *dst, const uint32_t *count, const uint32_t *flags, uint32_t cap, float *outT, int *outTri, uint32_t *heads,
+                                   uint32_t capOut = 0);   // capOut != 0 (RT_HYBRID_CHECK): entries of outT / outTri, checked before every store
 void rt_wave_debug_trace(hipStream_t st, int cus, int treeDepth, const rtd::DevFrame *dFrame, const rtd::DevScene &hostScene, bool any, const float4 *o, const float4 *d,
                          const float *tm, const uint32_t *liveCount, uint32_t n, float *outT, int *outTri, uint8_t *outOcc, uint32_t *heads);
 size_t rt_wave_head_words();

@@ -179,7 +179,10 @@ def test_staged_hybrid_equals_the_megakernel(budget_mb, w, h, spp, bounces, extr
     import os
     import subprocess
     import sys
-    env = dict(os.environ, RT_QUEUE_BUDGET_MB=str(budget_mb), **extra)
+    # RT_HYBRID_CHECK=1: every staged-record, thread-list, queue and log store of the staged pipeline proves its index against the capacity its array
+    # was allocated with and raises a flag instead of storing (rt_hybrid.hip hb_ok; the frame then ends with RT_ERR_STATE) -- the fence around the one
+    # GPU memory fault this pipeline has produced, in an uncommitted working tree of round 4 at exactly the second parametrisation
+    env = dict(os.environ, RT_QUEUE_BUDGET_MB=str(budget_mb), RT_HYBRID_CHECK="1", **extra)
     r = subprocess.run([sys.executable, "-c", _STAGED_CODE, str(w), str(h), str(spp), str(bounces)], cwd=str(scenes.ROOT), env=env, capture_output=True, text=True, timeout=900)
     assert "STAGED-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
