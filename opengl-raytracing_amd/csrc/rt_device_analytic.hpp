@@ -59,8 +59,17 @@ RT_DEV bool intersectSphere(float eps, V3 ro, V3 rd, V3 c, float r, Hit &h, int 
     h.mat = matId;
     return true;
 }
+// Inlining policy of the analytic scene's four big functions.  The megakernel keeps them as calls (its analytic branch is cold next to the BVH branch); a kernel
+// that does nothing else may define RT_ANALYTIC_LEAF / RT_ANALYTIC_MID before including this header (rt_hybrid.hip, round 5): as calls, the Replay state, every Hit
+// and every out-parameter live in scratch memory and each call saves and restores registers there (profiles/r05_hybrid_pmc.txt).
+#ifndef RT_ANALYTIC_LEAF
+#define RT_ANALYTIC_LEAF __noinline__      // traceAnalyticCore, traceScene: ~40 call sites per sample
+#endif
+#ifndef RT_ANALYTIC_MID
+#define RT_ANALYTIC_MID __noinline__       // directLightA, oneBounceGIAnalytic
+#endif
 template <bool COUNT>
-__device__ __noinline__ bool traceAnalyticCore(const RtUniforms &u, V3 ro, V3 rd, bool includeGlass, bool includeMarker, Hit &hit,
+__device__ RT_ANALYTIC_LEAF bool traceAnalyticCore(const RtUniforms &u, V3 ro, V3 rd, bool includeGlass, bool includeMarker, Hit &hit,
                                                Work &w) {   // :132-167
     if (COUNT) w.raysAnalytic++;
     hit.t = u.inf;
@@ -84,7 +93,7 @@ __device__ __noinline__ bool traceAnalyticCore(const RtUniforms &u, V3 ro, V3 rd
 // whose answers only scale radiance.  The staged pipeline speculates "miss" for every open query alike; when a speculation fails, the
 // answers recorded behind a failed GEOMETRIC query are void (their rays were built from the wrong hit), those behind a visibility query are not.
 template <bool COUNT>
-__device__ __noinline__ bool traceScene(const Frag &F, V3 ro, V3 rd, bool includeGlass, bool includeMarker, Hit &hit, Work &w, bool geometric = false) {
+__device__ RT_ANALYTIC_LEAF bool traceScene(const Frag &F, V3 ro, V3 rd, bool includeGlass, bool includeMarker, Hit &hit, Work &w, bool geometric = false) {
     const RtUniforms &u = *F.u;
     bool any = traceAnalyticCore<COUNT>(u, ro, rd, includeGlass, includeMarker, hit, w);
     if (u.useBVH == RT_SCENE_HYBRID && F.rp) {
@@ -137,7 +146,7 @@ __device__ __noinline__ bool traceScene(const Frag &F, V3 ro, V3 rd, bool includ
 // directLight, rt_lighting.glsl:313-395 (analytic occlusion branch of occludedToward :55-58,
 // sunDirect :133-135, pointDirect :203-205).
 template <bool COUNT>
-__device__ __noinline__ V3 directLightA(const Frag &F, const Hit &h, int frame, V3 Vdir, Work &w) {
+__device__ RT_ANALYTIC_MID V3 directLightA(const Frag &F, const Hit &h, int frame, V3 Vdir, Work &w) {
     const RtUniforms &u = *F.u;
     V3 N = normalize(h.n);
     MaterialProps mat = getMaterial(u, h.mat);
@@ -219,7 +228,7 @@ __device__ __noinline__ V3 directLightA(const Frag &F, const Hit &h, int frame, 
 //   result += (T_k * F) * Li;   T_{k+1} = (T_k * F) * giScaleAnalytic.           Same operations, same order as the parity checker's CPU restatement.
 constexpr int kMaxGiBounces = 8;
 template <bool COUNT>
-__device__ __noinline__ V3 oneBounceGIAnalytic(const Frag &F, const Hit &h0, int frame, int seed, Work &w) {
+__device__ RT_ANALYTIC_MID V3 oneBounceGIAnalytic(const Frag &F, const Hit &h0, int frame, int seed, Work &w) {
     const RtUniforms &u = *F.u;
     V3 result = mk3(0.0f), T = mk3(1.0f);
     Hit h = h0;

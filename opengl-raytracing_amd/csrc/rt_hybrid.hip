@@ -24,6 +24,13 @@
 #include <string>
 
 #include "../../include/rt_mi355.h"
+// Round 5: the shading code inlined into this kernel (rt_device_analytic.hpp "Inlining policy").  As calls -- the megakernel's form -- the Replay state and every Hit
+// lived in scratch memory and each of a sample's ~40 scene queries saved and restored registers there: 1.8e10 scratch instructions and 3.6 TB/s of fabric traffic
+// in a kernel that used 18 % of its vector issue slots (profiles/r05_hybrid_pmc.txt).
+#ifndef RT_HYBRID_CALLS
+#define RT_ANALYTIC_LEAF __forceinline__
+#define RT_ANALYTIC_MID __forceinline__
+#endif
 #include "rt_device_analytic.hpp"
 #include "rt_wave.hpp"
 
@@ -97,8 +104,10 @@ RT_DEV uint32_t wave_excl_scan(uint32_t v, uint32_t lane, uint32_t &total) {
     return incl - v;
 }
 
-// Five waves per SIMD: 96 VGPRs and 704 bytes of scratch per lane.  The shading code is long and cold in most of its registers; measured on MI355X
-// (1080p, 16 spp, 4 bounces, all shading passes of a frame): 53.8 / 41.1 / 38.0 / 36.4 / 39.1 ms at 2 (no bound: 225 VGPRs) / 3 / 4 / 5 / 6 waves per SIMD.
+// Four waves per SIMD: 128 VGPRs and 160 bytes of scratch per lane, with the shading code INLINED (round 5; as calls it was 96 VGPRs + 800 B at five waves, and the
+// scratch traffic of ~40 calls per sample was what the kernel waited on: run B 30.0 -> 17.8 ms per frame).  Measured on MI355X (1080p, 16 spp, 4 bounces, whole
+// frame): 18.7 / 17.8 / 18.7 / 19.9 ms at 3 / 4 / 5 / 6 waves per SIMD (72 / 160 / 328 / 400 B of scratch); round 3, as calls, shading passes only: 41.1 / 38.0 /
+// 36.4 / 39.1 ms at 3 / 4 / 5 / 6.
 // Persistent: a fixed grid walks the tiles of 256 threads (first pass of a chunk: thread = (sample, slot) in order; later passes: the dense list of threads
 // whose speculation failed), so that the list length can stay on the device and every workgroup owns one staging area.
 template <int WAVES>
@@ -352,7 +361,7 @@ struct RtHybrid {
     void *arena = nullptr, *staging = nullptr;
     size_t arenaBytes = 0, stagingBytes = 0;
     int gridShade = 0;
-    int waves = 5;            // launch bound of the shading kernel (waves per SIMD), RT_HYBRID_WAVES
+    int waves = 4;            // launch bound of the shading kernel (waves per SIMD), RT_HYBRID_WAVES
     uint32_t *cnt = nullptr, *heads = nullptr;
     uint32_t *hostCnt = nullptr;       // pinned
     unsigned long long passes = 0, launches = 0, redone = 0;
@@ -408,9 +417,9 @@ int rt_hybrid_render(RtHybrid *h, RtContext *ctx, hipStream_t st, const DevFrame
     }
     if (h->gridShade == 0) {
         int perCU = 0;
-        h->waves = 5;
-        if (const char *e = getenv("RT_HYBRID_WAVES")) h->waves = atoi(e) == 4 ? 4 : atoi(e) == 6 ? 6 : atoi(e) == 3 ? 3 : 5;   // EXPERIMENT: register budget of the shading kernel
-        auto kfn = h->waves == 3 ? k_hybrid_shade<3> : h->waves == 4 ? k_hybrid_shade<4> : h->waves == 6 ? k_hybrid_shade<6> : k_hybrid_shade<5>;
+        h->waves = 4;
+        if (const char *e = getenv("RT_HYBRID_WAVES")) h->waves = atoi(e) == 5 ? 5 : atoi(e) == 6 ? 6 : atoi(e) == 3 ? 3 : 4;   // EXPERIMENT: register budget of the shading kernel
+        auto kfn = h->waves == 3 ? k_hybrid_shade<3> : h->waves == 5 ? k_hybrid_shade<5> : h->waves == 6 ? k_hybrid_shade<6> : k_hybrid_shade<4>;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kfn, 256, 0) != hipSuccess || perCU < 1) perCU = 1;
         h->gridShade = h->cus * std::min(perCU, 8);
     }
@@ -500,7 +509,7 @@ int rt_hybrid_render(RtHybrid *h, RtContext *ctx, hipStream_t st, const DevFrame
                 H_TRY(hipMemsetAsync(h->cnt + C_REC * kCnt, 0, sizeof(uint32_t), st));
                 H_TRY(hipMemsetAsync(h->cnt + C_TILE * kCnt, 0, sizeof(uint32_t), st));
                 rt_stage_begin(ctx, ST_COMBINE, st);
-                auto kfn = h->waves == 3 ? k_hybrid_shade<3> : h->waves == 4 ? k_hybrid_shade<4> : h->waves == 6 ? k_hybrid_shade<6> : k_hybrid_shade<5>;
+                auto kfn = h->waves == 3 ? k_hybrid_shade<3> : h->waves == 5 ? k_hybrid_shade<5> : h->waves == 6 ? k_hybrid_shade<6> : k_hybrid_shade<4>;
                 hipLaunchKernelGGL(kfn, dim3((unsigned)h->gridShade), dim3(256), 0, st, dFrame, hb, launched == 0 ? 0 : 1);
                 hipLaunchKernelGGL(k_hybrid_note, dim3(1), dim3(1), 0, st, h->cnt);
                 rt_stage_end(ctx, ST_COMBINE, 2, st);
