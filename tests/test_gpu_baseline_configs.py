@@ -449,6 +449,54 @@ def test_config4_scene_spp_and_accumulation_together(orc):
         assert np.array_equal(g[y0:y1, x0:x1], w_[y0:y1, x0:x1])
 
 
+def test_config4_at_its_own_size(orc):
+    """BASELINE configs[4] AS WRITTEN on one GPU: the 1 M-triangle multi-object scene, 1920x1080, 64 spp, temporal accumulation over frames
+    0..31 -- the run DESIGN.md times at ~250 ms per frame and nobody had looked at.  Rendered in batches of eight through rt_render_frames (each batch's ray
+    queues are several chunks of the 16 GB budget; the any-hit launches walk the quantised nodes) and compared with
+      (i)  the same 32 frames rendered one rt_render_frame at a time by a second context: all four targets, every pixel, bit for bit;
+      (ii) the oracle on a 32 x 16 window through geometry with the whole 32-frame history chain (64 spp x 512 pixels x 32 frames = 1 M oracle samples; the
+           weights of rt_taa.glsl:91-104 switch at frames 8 and 32): bit for bit.
+    About 20 s of GPU time and 10 s of host time (scene + tree build)."""
+    v, f = rt.meshgen.million_triangle_scene()
+    nodes, tris = rt.build_bvh(rt.gather_triangles(v, f, np.eye(4, dtype=np.float32).reshape(-1)))
+    assert tris.shape[0] == 1_000_000
+    faces = scenes.env_faces("Sky_01")
+    W, H, FRAMES = 1920, 1080, 32
+    p = rt.default_render_params()
+    p.sppPerFrame = 64
+    cam = scenes.camera("default")
+    us = [rt.frame_uniforms(p, cam, W, H, f_, True, nodes.shape[0], tris.shape[0]) for f_ in range(FRAMES)]
+    with rt.Renderer() as many:
+        many.upload_bvh(nodes, tris)
+        many.upload_env(faces)
+        many.resize(W, H)
+        for b in range(0, FRAMES, 8):
+            many.render_frames(us[b:b + 8])
+        got = many.read_all()
+        hit_pixels = many.traced_rays().hitPixels
+    assert hit_pixels > FRAMES * W * H // 16
+    with rt.Renderer() as one:                   # (after the first context is gone: each takes tens of GB of ray queues at this size)
+        one.upload_bvh(nodes, tris)
+        one.upload_env(faces)
+        one.resize(W, H)
+        for u in us:
+            one.render_frame(u)
+        for a, b in zip(got, one.read_all()):
+            assert np.array_equal(a, b)
+    # a window that shows geometry: the row band and column run with the most hit pixels in the position target
+    geo = got[2][..., 3] != 0
+    y0 = int(np.argmax(np.convolve(geo.sum(axis=1), np.ones(16, int), "valid")))
+    x0 = int(np.argmax(np.convolve(geo[y0:y0 + 16].sum(axis=0), np.ones(32, int), "valid")))
+    x1, y1 = x0 + 32, y0 + 16
+    assert geo[y0:y1, x0:x1].sum() > 256
+    prev = None
+    for u in us:
+        want, _ = orc.render(u, nodes, tris, faces, prev, region=(x0, y0, x1, y1), nthreads=16)
+        prev = want[0]
+    for g, w_ in zip(got, want):
+        assert np.array_equal(g[y0:y1, x0:x1], w_[y0:y1, x0:x1])
+
+
 def test_shared_ray_arenas_and_memory_info(orc):
     """Round 4: the ray-queue arenas are shared by the frame lanes (two for four lanes; a launch set of several chunks takes its lane's own) and
     rt_get_memory_info reports them.  Twelve batches of four frames keep all four lanes and both arenas turning over; the last frame equals the
