@@ -230,7 +230,8 @@ int rt_present(RtContext *ctx, const RtPresentParams *p, uint8_t *dstRGBA8);
 /* Tile-parallel plumbing for a host that runs the exchange itself (e.g. through torch.distributed on these device pointers;
  * the library's own RCCL path is rt_comm_init / rt_gather_frame / rt_exchange_history below).
  * Local layout: [localTile][RT_TILE_PIXELS][channels] halfs, localTile = globalTile / worldSize for
- * globalTile % worldSize == rank, globalTile = tileY * tilesX + tileX. */
+ * globalTile % worldSize == rank, globalTile = tileY * tilesX + (tileX + rowShift) % tilesX, rowShift = 0 for worldSize 1 and
+ * (11 * tileY) % tilesX otherwise: a rank's tiles are scattered over the frame, not fixed columns (csrc/rt_frame.hpp, tiles.py). */
 int rt_local_target(RtContext *ctx, int which, void **devPtr, size_t *bytes);
 /* bytes every rank must contribute so that all ranks send equally sized blocks (padded local size) */
 int rt_gather_block_bytes(const RtContext *ctx, int which, size_t *bytes);

@@ -161,7 +161,7 @@ __global__ void k_assemble(const void *gathered, void *dst, FrameGeom g, int cha
     if (i >= g.W * g.H) return;
     int x = i % g.W, y = i / g.W;
     int tx = x >> 4, ty = y >> 4;
-    int t = ty * g.tilesX + tx;
+    int t = tile_index(g, tx, ty);
     int owner = t % g.world, local = t / g.world;
     int lx = x & 15, ly = y & 15;
     int q = (lx >> 3) | ((ly >> 3) << 1);

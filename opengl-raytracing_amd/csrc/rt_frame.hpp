@@ -2,8 +2,11 @@
 // layout, and the launcher prototypes that connect rt_api.hip to the kernel translation units.
 //
 // Framebuffer layout in HBM ("tile-major"): the W x H frame is cut into 16x16-pixel tiles,
-// globalTile = tileY * tilesX + tileX.  Rank r of a world of n owns the tiles with
-// globalTile % n == r and stores them densely: localTile = globalTile / n.  A tile is 256
+// globalTile = tileY * tilesX + (tileX + rowShift(tileY)) % tilesX.  Rank r of a world of n owns the tiles with
+// globalTile % n == r and stores them densely: localTile = globalTile / n.  rowShift (round 5) is 0 on one
+// GPU and 11 * tileY mod tilesX on several: tilesX is 120 at 1080p and 240 at 4K -- a multiple of every world size from 2 to 8 but
+// 7 -- so without it a rank owned fixed 16-pixel COLUMNS of the frame and anything with vertical structure at that period landed on
+// one rank; with it a rank's tiles move 11 columns (coprime to every world size up to 10) from row to row.  A tile is 256
 // consecutive pixels = one 256-thread workgroup; inside it each 64-pixel run is one 8x8 block =
 // one wavefront, so a wave's loads/stores of a target are one contiguous 512-byte (RGBA16F) run
 // and its rays start out spatially coherent.
@@ -45,13 +48,23 @@ struct Targets {
 
 RT_DEV int sub_frame_of_tile(const FrameGeom &g, int localTile) { return g.batch > 1 ? localTile / max(g.nLocalTiles, 1) : 0; }
 RT_DEV int sub_frame_of_slot(const FrameGeom &g, uint32_t slot) { return sub_frame_of_tile(g, (int)(slot >> 8)); }
+// the tile deal: global tile index of tile (tx, ty) and back.  Row ty's tiles are numbered from column rowShift on (see the header comment).
+constexpr int kTileRowShift = 11;
+__host__ __device__ inline int tile_row_shift(const FrameGeom &g, int ty) { return g.world > 1 ? (ty * kTileRowShift) % g.tilesX : 0; }
+__host__ __device__ inline int tile_index(const FrameGeom &g, int tx, int ty) { return ty * g.tilesX + (tx + tile_row_shift(g, ty)) % g.tilesX; }
+__host__ __device__ inline void tile_xy(const FrameGeom &g, int t, int &tx, int &ty) {
+    ty = t / g.tilesX;
+    tx = (t % g.tilesX + g.tilesX - tile_row_shift(g, ty)) % g.tilesX;
+}
 RT_DEV bool pixel_of_slot(const FrameGeom &g, int localTile, int tid, int &x, int &y) {
     if (g.batch > 1) {
         if (localTile >= g.nLocalTiles * g.batch) { x = y = 0; return false; }
         localTile %= max(g.nLocalTiles, 1);
     }
     int t = localTile * g.world + g.rank;
-    int tx = t % g.tilesX, ty = t / g.tilesX;
+    if (t >= g.nTiles) { x = y = 0; return false; }   // padding of the last local tile row of this rank
+    int tx, ty;
+    tile_xy(g, t, tx, ty);
     int q = tid >> 6, lane = tid & 63;
     x = tx * 16 + (q & 1) * 8 + (lane & 7);
     y = ty * 16 + (q >> 1) * 8 + (lane >> 3);
@@ -60,7 +73,7 @@ RT_DEV bool pixel_of_slot(const FrameGeom &g, int localTile, int tid, int &x, in
 // slot of pixel (x,y) if this rank owns it, else -1
 RT_DEV int slot_of_pixel(const FrameGeom &g, int x, int y) {
     int tx = x >> 4, ty = y >> 4;
-    int t = ty * g.tilesX + tx;
+    int t = tile_index(g, tx, ty);
     if (t % g.world != g.rank) return -1;
     int lx = x & 15, ly = y & 15;
     int q = (lx >> 3) | ((ly >> 3) << 1);
@@ -82,7 +95,7 @@ RT_DEV V4 unpack_half4(uint2 r) {
 // slot of pixel (x,y) in a rank-major array of gathered blocks (blockSlots slots per rank), whoever owns it
 RT_DEV int slot_in_gathered(const FrameGeom &g, int x, int y, int blockSlots) {
     int tx = x >> 4, ty = y >> 4;
-    int t = ty * g.tilesX + tx;
+    int t = tile_index(g, tx, ty);
     int lx = x & 15, ly = y & 15;
     int q = (lx >> 3) | ((ly >> 3) << 1);
     return (t % g.world) * blockSlots + (t / g.world) * 256 + q * 64 + (ly & 7) * 8 + (lx & 7);

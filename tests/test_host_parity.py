@@ -206,3 +206,29 @@ def test_host_entry_points_reject_bad_input(tmp_path):
     v, idx = rt.load_obj(tmp_path / "ngon.obj")
     assert v.shape == (n, 3) and idx.size == (n - 2) * 3 and idx.max() == n - 1
     assert np.array_equal(idx.reshape(-1, 3)[:, 0], np.zeros(n - 2, np.uint32))
+
+
+def test_tile_deal_scatters_a_ranks_tiles():
+    """at 1080p (tilesX = 120) and 4K (240) the number of tile columns is a multiple of nearly every world size, so `tile % world` alone gave
+    every rank fixed 16-pixel COLUMNS of the frame.  With the row shift of csrc/rt_frame.hpp (11 tile columns per tile row) every rank owns tiles in every tile
+    column and in every tile row, its share differs from the others' by at most one tile, and the numpy mirror round-trips (pack_local -> assemble)."""
+    from opengl_raytracing_amd import tiles
+    for w, h in ((1920, 1080), (3840, 2160), (640, 360)):
+        for world in (2, 3, 4, 5, 6, 8):
+            owner, slot = tiles.slot_map(w, h, world)
+            tile_owner = owner[::16, ::16]                       # one entry per tile
+            counts = np.bincount(tile_owner.ravel(), minlength=world)
+            assert counts.max() - counts.min() <= 1, (w, h, world, counts)
+            for r in range(world):
+                mine = tile_owner == r
+                assert mine.any(axis=0).all(), (w, h, world, r, "a tile column without this rank")
+                assert mine.any(axis=1).all(), (w, h, world, r, "a tile row without this rank")
+                assert mine.all(axis=0).sum() == 0                # and no column it owns alone
+            # slots are dense per rank: every slot index below the rank's tile count x 256 is used exactly once
+            for r in range(world):
+                s = np.sort(slot[owner == r])
+                full_tiles = (owner == r).sum()
+                assert np.array_equal(np.unique(s), s) and s.size == full_tiles
+    # world of one: the plain row-major tile order, as in rounds 1-4
+    owner, slot = tiles.slot_map(64, 48, 1)
+    assert owner.max() == 0 and slot[0, 16] == 256 and slot[16, 0] == 4 * 256
