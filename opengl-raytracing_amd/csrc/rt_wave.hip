@@ -419,8 +419,10 @@ RT_DEV void pin(v4f &v) { asm volatile("" : "+v"(v)); }
 template <int CTRL> RT_DEV int quad_bcast_i(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true); }
 // one dword of a butterfly stage: a = keepA ? x : partner(y), b = keepB ? y : partner(x).  `a` is written while x, y are still read
 // (early clobber); `b` is written by the last instruction and may reuse an input's register, so a stage needs one spare register, not eight.
+// (the s_nop 1 sits INSIDE the block: a DPP source written by a VALU instruction needs two wait states, the assembler does not insert them in inline asm, and
+// between two asm statements the compiler may place a copy for an operand -- ADVICE r04.  The s_mov that follows is a third instruction in between.)
 #define RT_QT_PAIR(PERM, X, Y, A, B)                                                                                               \
-    asm volatile("s_mov_b64 vcc, %[ka]\n\tv_cndmask_b32_dpp %[a], %[y], %[x], vcc quad_perm:" PERM " row_mask:0xf bank_mask:0xf\n\t" \
+    asm volatile("s_nop 1\n\ts_mov_b64 vcc, %[ka]\n\tv_cndmask_b32_dpp %[a], %[y], %[x], vcc quad_perm:" PERM " row_mask:0xf bank_mask:0xf\n\t" \
                  "s_mov_b64 vcc, %[kb]\n\tv_cndmask_b32_dpp %[b], %[x], %[y], vcc quad_perm:" PERM " row_mask:0xf bank_mask:0xf"      \
                  : [a] "=&v"(A), [b] "=v"(B) : [x] "v"(X), [y] "v"(Y), [ka] "s"(keepA), [kb] "s"(keepB) : "vcc")
 RT_DEV void quad_transpose(v4f &r0, v4f &r1, v4f &r2, v4f &r3) {
@@ -428,7 +430,6 @@ RT_DEV void quad_transpose(v4f &r0, v4f &r1, v4f &r2, v4f &r3) {
     v4f a0, a1, a2, a3;
     {
         const unsigned long long keepA = 0x5555555555555555ull, keepB = 0xAAAAAAAAAAAAAAAAull;   // lane bit 0 clear / set
-        asm volatile("s_nop 1");   // a DPP source written by a VALU instruction needs two wait states (not inserted inside inline asm)
         RT_QT_PAIR("[1,0,3,2]", r0.x, r1.x, a0.x, a1.x); RT_QT_PAIR("[1,0,3,2]", r0.y, r1.y, a0.y, a1.y);
         RT_QT_PAIR("[1,0,3,2]", r0.z, r1.z, a0.z, a1.z); RT_QT_PAIR("[1,0,3,2]", r0.w, r1.w, a0.w, a1.w);
         RT_QT_PAIR("[1,0,3,2]", r2.x, r3.x, a2.x, a3.x); RT_QT_PAIR("[1,0,3,2]", r2.y, r3.y, a2.y, a3.y);

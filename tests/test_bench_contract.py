@@ -39,6 +39,7 @@ def test_bench_line_contract():
     c = d["config"]
     assert c["batched_equals_frame_by_frame"] is True and c["color0_sha256"] == c["color0_sha256_frame_by_frame"] and len(c["color0_sha256"]) == 64
     assert c["ms_per_step_frame_by_frame"] > 0
+    assert c["stage_events_in_timed_region"] is False and c["stage_frames"] >= 1      # one GPU: the stage spans come from an untimed pass
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert 0 < r["frac"] <= 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
