@@ -434,7 +434,7 @@ def main():
     # ---- diagnostics, untimed, single GPU: (1) one launch set in flight (RT_LANES=1) in the SAME batched mode as the timed run: what each
     # stage costs when it has the GPU to itself -- with 3-4 batches in flight an event span also contains the time a kernel shares the GPU
     # with other batches' kernels; this pass gives the kernels' own durations, which is what rocprofv3's kernel trace reports
-    # (profiles/r04_*kernel_stats*.csv).  (2) the same with the instrumented traversal kernels (RT_TRACE_STATS=2): gather loads after merging the
+    # (profiles/r05_*kernel_stats*.csv).  (2) the same with the instrumented traversal kernels (RT_TRACE_STATS=2): gather loads after merging the
     # lanes of a wave that stand on the same record -- the unit the vector L1's one-access-per-clock ceiling applies to.
     serial, merged = None, None
     if world == 1 and not args.hybrid and not args.no_diagnostics:
@@ -513,12 +513,12 @@ def main():
             ref_layout = {"algorithmic_bytes_per_launch": ref_bytes, "bytes_per_s_GB": ref_bytes / (avg_ms * 1e-3) / 1e9, "frac": None,
                           "note": "SURVEY 8d units (48 B x the reference loop's nodeFetch + triFetch for these rays, megakernel counting pass); "
                                   "not bytes this implementation moves, so no fraction of a hardware peak is formed from it"}
-        # HBM bytes of that kernel per launch from the PMC passes of tools/r03_profile.sh (round 4: tag r04p, summarised by tools/r04_summarize.py) (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+        # HBM bytes of that kernel per launch from the PMC passes of tools/r03_profile.sh (round 5: tag r05fin, summarised by tools/r05_summarize.py) (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
         # passes over THIS command in its batched mode, gfx950 2x fetch correction).  PMC cannot be collected inside this run: the figure is
         # accepted only when the kernel sources it was measured on are the ones running now, else it is dropped.
         traffic, traffic_src = None, None
         kmap = {"trace_shadow": "DualQueueSrc, true", "trace_gi": "QueueSrc, false", "trace_primary": "PrimarySrc", "trace_ao": "k_trace_packets"}
-        tj = ROOT / "profiles" / ("r04_traffic_%s.json" % ("1m" if args.scene == "1m" else "bunny"))
+        tj = ROOT / "profiles" / ("r05_traffic_%s.json" % ("1m" if args.scene == "1m" else "bunny"))
         if world == 1 and tj.exists() and name in kmap and (W, H, SPP, B) == (1920, 1080, 4, 8) and not args.obj:
             tjd = json.load(open(tj))
             if tjd.get("kernel_source_sha256") == kernel_source_sha():
@@ -549,7 +549,7 @@ def main():
                       "peak_source": "one TCP cache access per clock and CU x 256 CUs x 2.4 GHz (profiles/r02_gather_microbench_pmc.txt: 0.80-0.99 measured "
                                      "with divergent 16-byte lane-loads; lanes reading the same 16 bytes count once)",
                       "merge_factor_source": "counted by the instrumented traversal kernels over one batch of this workload (distinct records per wave "
-                                             "step / lanes); the PMC figure of the same launches is in profiles/r04_derived.txt"}
+                                             "step / lanes); the PMC figure of the same launches is in profiles/r05_derived.txt"}
         roofline = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                     "traffic_frac_of_peak": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
