@@ -289,8 +289,8 @@ int rt_reset_counters(RtContext *ctx);
  * 4 MB the any-hit launches walk its quantised form instead: bytesNodes4 is then 64 bytes per four-child record + 32
  * bytes of exact box per leaf. */
 #define RT_SCENE_QNODES_REJECTED 1   /* quantised any-hit nodes were asked for (tree size or RT_QNODES) but could not be built: the exact nodes are walked */
-#define RT_SCENE_IMPLICIT 4          /* every leaf sits at one depth: the traversal launches walk 48-byte records without child references */
-#define RT_SCENE_NOT_FUSED 2         /* some inner box is not the union of its children's: closest-hit rays walk the 64-byte records, not the fused ones */
+#define RT_SCENE_IMPLICIT 4          /* RT_IMPLICIT=1 and every leaf sits at one depth: closest-hit rays walk 48-byte records without child references */
+#define RT_SCENE_NOT_FUSED 2         /* RT_FUSED=1 but some inner box is not the union of its children's: closest-hit rays walk the 64-byte records, not the fused ones */
 typedef struct RtSceneInfo {
     int32_t nNodes, nTris, nInner, treeDepth, nWide4, nPairs;
     uint64_t bytesNodes2, bytesNodes4, bytesPairs, bytesTris;

@@ -45,6 +45,7 @@ struct RtContext {
     float4 *dWNodes = nullptr, *dW4 = nullptr, *dTris = nullptr, *dWNodesW = nullptr, *dPairs = nullptr;
     float4 *dQ4 = nullptr, *dLeafBox = nullptr;   // RT_QNODES: quantised any-hit nodes + the leaves' exact boxes
     float4 *dWF = nullptr;           // fused closest-hit records (round 5), null when the tree's boxes are not the unions of their children's
+    float4 *dIN4 = nullptr, *dIQ4 = nullptr, *dILeafBox = nullptr;   // ... and the any-hit walk's four-wide records, exact (96 B) and quantised (48 B + the leaves' exact boxes by ordinal)
     float4 *dIN2 = nullptr, *dIPairs = nullptr;   // implicit records (round 5): 48-byte two-child records without references + the pair records in leaf order; null unless every leaf sits at depth implD
     int implD = 0, implR = 0;
     size_t nFused = 0;
@@ -230,6 +231,7 @@ DevScene make_dev_scene(const RtContext *c) {
     s.wnodesW = c->dWNodesW;
     s.wF = c->dWF;
     s.iN2 = c->dIN2; s.iPairs = c->dIPairs; s.implD = c->implD; s.implR = c->implR;
+    s.iN4 = c->dIN4; s.iQ4 = c->dIQ4; s.iLeafBox = c->dILeafBox;
     s.pairs = c->dPairs;
     s.rootRefW = c->rootRefW;
     s.tris = c->dTris;
@@ -411,6 +413,9 @@ void rt_destroy(RtContext *c) {
     if (c->dWF) (void)hipFree(c->dWF);
     if (c->dIN2) (void)hipFree(c->dIN2);
     if (c->dIPairs) (void)hipFree(c->dIPairs);
+    if (c->dIN4) (void)hipFree(c->dIN4);
+    if (c->dIQ4) (void)hipFree(c->dIQ4);
+    if (c->dILeafBox) (void)hipFree(c->dILeafBox);
     if (c->dPairs) (void)hipFree(c->dPairs);
     if (c->dTris) (void)hipFree(c->dTris);
     if (c->dEnv) (void)hipFree(c->dEnv);
@@ -435,7 +440,10 @@ int rt_upload_bvh(RtContext *c, const float *nodes12, int nNodes, const float *t
     if (c->dWF) (void)hipFree(c->dWF);
     if (c->dIN2) (void)hipFree(c->dIN2);
     if (c->dIPairs) (void)hipFree(c->dIPairs);
-    c->dIN2 = c->dIPairs = nullptr; c->implD = c->implR = 0;
+    if (c->dIN4) (void)hipFree(c->dIN4);
+    if (c->dIQ4) (void)hipFree(c->dIQ4);
+    if (c->dILeafBox) (void)hipFree(c->dILeafBox);
+    c->dIN2 = c->dIPairs = c->dIN4 = c->dIQ4 = c->dILeafBox = nullptr; c->implD = c->implR = 0;
     if (c->dPairs) (void)hipFree(c->dPairs);
     if (c->dTris) (void)hipFree(c->dTris);
     c->dWNodes = c->dW4 = c->dTris = c->dWNodesW = c->dPairs = c->dQ4 = c->dLeafBox = c->dWF = nullptr;
@@ -825,7 +833,9 @@ int rt_upload_bvh(RtContext *c, const float *nodes12, int nNodes, const float *t
     // here for whatever was uploaded; a tree that fails the check keeps the 64-byte records (RT_SCENE_NOT_FUSED in RtSceneInfo.flags).
     std::vector<float> wF;
     {
-        bool okF = nd[0].count <= 0 && !(getenv("RT_FUSED_BUILD") && atoi(getenv("RT_FUSED_BUILD")) == 0);   // RT_FUSED_BUILD=0: tests of the fallback
+        // built only where the option is on (both forms are measured options, off by default: no second and third copy of the tree in device memory otherwise)
+        const bool wantF = getenv("RT_FUSED") && atoi(getenv("RT_FUSED")) != 0;
+        bool okF = wantF && nd[0].count <= 0;
         for (int i = 0; i < nNodes && okF; ++i) {
             if (nd[(size_t)i].count > 0) continue;
             const float *P = nodes12 + (size_t)i * 12, *L = nodes12 + (size_t)nd[(size_t)i].left * 12, *R = nodes12 + (size_t)nd[(size_t)i].right * 12;
@@ -869,7 +879,7 @@ int rt_upload_bvh(RtContext *c, const float *nodes12, int nNodes, const float *t
                 if (!okF) break;
             }
         }
-        if (!okF) { wF.clear(); if (nd[0].count <= 0) c->sceneFlags |= RT_SCENE_NOT_FUSED; }
+        if (!okF) { wF.clear(); if (wantF && nd[0].count <= 0) c->sceneFlags |= RT_SCENE_NOT_FUSED; }
     }
     // Round 5 -- implicit records.  What the traversal launches cost is their 16-byte lane-loads (one vector-L1 lookup each), and a 64-byte
     // two-child record spends one of its four on two child references.  The reference's builder splits every range at its middle and stops at <= 8 triangles
@@ -879,9 +889,10 @@ int rt_upload_bvh(RtContext *c, const float *nodes12, int nNodes, const float *t
     // d - popcount(p) + (p << (D - d)) (a left child sits next to its parent, as in the reference's own numbering); a leaf's triangle-pair records at
     // p * R (R = the most records any leaf owns), the leaf's triangle count in the spare word of its first record.  Visiting order, boxes and triangle tests
     // are those of the 64-byte records.  Checked here for whatever tree was uploaded (all leaves at one depth <= 23); others keep the explicit records.
-    std::vector<float> iN2, iPairs;
+    std::vector<float> iN2, iPairs, iN4, iLeafBox;
+    std::vector<uint32_t> iQ4;
     int implD = 0, implR = 0;
-    if (nd[0].count <= 0 && !(getenv("RT_IMPLICIT_BUILD") && atoi(getenv("RT_IMPLICIT_BUILD")) == 0)) {
+    if (nd[0].count <= 0 && getenv("RT_IMPLICIT") && atoi(getenv("RT_IMPLICIT")) != 0) {
         struct E { int node; int d; uint32_t p; };
         std::vector<E> st{{0, 0, 0u}};
         std::vector<int> nodeD((size_t)nNodes, -1);
@@ -927,6 +938,75 @@ int rt_upload_bvh(RtContext *c, const float *nodes12, int nNodes, const float *t
                 }
             }
             implD = D; implR = maxRec;
+            // ... and the any-hit walk's four-wide records in the same naming: an even-depth node (d, p) has the children (d + 2, 4p + j), j = 0..3 (or, when d + 1 == D,
+            // the two leaves 2p, 2p + 1), so the record is the four child boxes alone, component-wise: 96 bytes, SIX loads instead of seven, at the node's own
+            // pre-order position (odd-depth slots of the array stay empty and are never touched).  Where the quantised form is walked (trees beyond the L2) the same
+            // record in bytes: [origin.xyz, exponents] [lo.x lo.y lo.z hi.x] [hi.y hi.z - -] = 48 bytes, THREE loads instead of four, and the leaves' exact boxes at
+            // their ordinal p.
+            const bool wantQ = !q4.empty();
+            const float qnan = std::nanf("");
+            iN4.assign((((size_t)1 << D) - 1) * 24, 0.0f);
+            if (wantQ) { iQ4.assign((((size_t)1 << D) - 1) * 12, 0u); iLeafBox.assign(((size_t)1 << D) * 8, 0.0f); }
+            bool okI = true;
+            for (int i = 0; i < nNodes && okI; ++i) {
+                const int d = nodeD[(size_t)i];
+                if (d < 0) continue;
+                const N &n = nd[(size_t)i];
+                const uint32_t pth = nodeP[(size_t)i];
+                if (n.count > 0) {
+                    if (wantQ) { const float *b = nodes12 + (size_t)i * 12; const float box[8] = {b[0], b[1], b[2], b[4], b[5], b[6], 0.0f, 0.0f}; std::memcpy(&iLeafBox[(size_t)pth * 8], box, sizeof box); }
+                    continue;
+                }
+                if (d & 1) continue;
+                int kids[4] = {-1, -1, -1, -1};
+                if (d + 1 == D) { kids[0] = n.left; kids[1] = n.right; }
+                else { kids[0] = nd[(size_t)n.left].left; kids[1] = nd[(size_t)n.left].right; kids[2] = nd[(size_t)n.right].left; kids[3] = nd[(size_t)n.right].right; }
+                const size_t at = (size_t)d - (size_t)__builtin_popcount(pth) + ((size_t)pth << (D - d));
+                float *o = &iN4[at * 24];
+                for (int k = 0; k < 4; ++k) {
+                    const float *b = kids[k] >= 0 ? nodes12 + (size_t)kids[k] * 12 : nullptr;
+                    o[0 + k] = b ? b[0] : qnan; o[4 + k] = b ? b[1] : qnan; o[8 + k] = b ? b[2] : qnan;
+                    o[12 + k] = b ? b[4] : qnan; o[16 + k] = b ? b[5] : qnan; o[20 + k] = b ? b[6] : qnan;
+                }
+                if (!wantQ) continue;
+                // quantise as the explicit form does (above): origin = the children's common minimum, one power-of-two step per axis, bytes moved outward until the decoded
+                // box -- in the kernel's own expression fmaf(byte, 2^e, origin) -- contains the child's
+                uint32_t *q = &iQ4[at * 12];
+                float org[3], scale[3];
+                uint32_t exps = 0;
+                for (int a = 0; a < 3 && okI; ++a) {
+                    float lo = INFINITY, hi = -INFINITY;
+                    for (int k = 0; k < 4; ++k) if (kids[k] >= 0) { lo = std::min(lo, o[4 * a + k]); hi = std::max(hi, o[12 + 4 * a + k]); }
+                    if (!(lo <= hi)) { lo = hi = 0.0f; }
+                    int eb = 1;
+                    const double ext = ((double)hi - (double)lo) / 255.0;
+                    if (ext > 0.0) { int e2; (void)std::frexp(ext, &e2); eb = std::max(1, e2 - 1 + 127); }
+                    while (eb <= 254 && std::fmaf(255.0f, std::ldexp(1.0f, eb - 127), lo) < hi) ++eb;
+                    if (eb > 254) { okI = false; break; }
+                    org[a] = lo; scale[a] = std::ldexp(1.0f, eb - 127);
+                    exps |= (uint32_t)eb << (8 * a);
+                    std::memcpy(&q[a], &lo, 4);
+                }
+                if (!okI) break;
+                q[3] = exps;
+                for (int k = 0; k < 4; ++k) {
+                    if (kids[k] < 0) continue;
+                    for (int a = 0; a < 3; ++a) {
+                        const float lo = o[4 * a + k], hi = o[12 + 4 * a + k];
+                        int ql = (int)std::floor(((double)lo - (double)org[a]) / (double)scale[a]);
+                        ql = std::max(0, std::min(255, ql));
+                        while (ql > 0 && std::fmaf((float)ql, scale[a], org[a]) > lo) --ql;
+                        int qh = (int)std::ceil(((double)hi - (double)org[a]) / (double)scale[a]);
+                        qh = std::max(0, std::min(255, qh));
+                        while (qh < 255 && std::fmaf((float)qh, scale[a], org[a]) < hi) ++qh;
+                        if (std::fmaf((float)ql, scale[a], org[a]) > lo || std::fmaf((float)qh, scale[a], org[a]) < hi) okI = false;
+                        const int wl = 4 + a, wh = a == 0 ? 7 : 7 + a;      // words: lo.x lo.y lo.z hi.x | hi.y hi.z
+                        q[wl] |= (uint32_t)ql << (8 * k);
+                        q[wh] |= (uint32_t)qh << (8 * k);
+                    }
+                }
+            }
+            if (!okI) { iQ4.clear(); iLeafBox.clear(); }      // (the explicit quantised form passed the same checks, so this does not happen)
         }
     }
     if (depth > 32) return fail(c, RT_ERR_UNSUPPORTED, "rt_upload_bvh: tree depth %d exceeds the 32-entry traversal stack", depth);
@@ -942,6 +1022,14 @@ int rt_upload_bvh(RtContext *c, const float *nodes12, int nNodes, const float *t
         HIP_TRY(c, hipMalloc(&c->dIPairs, iPairs.size() * sizeof(float)));
         HIP_TRY(c, hipMemcpy(c->dIPairs, iPairs.data(), iPairs.size() * sizeof(float), hipMemcpyHostToDevice));
         c->implD = implD; c->implR = implR;
+        HIP_TRY(c, hipMalloc(&c->dIN4, iN4.size() * sizeof(float)));
+        HIP_TRY(c, hipMemcpy(c->dIN4, iN4.data(), iN4.size() * sizeof(float), hipMemcpyHostToDevice));
+        if (!iQ4.empty()) {
+            HIP_TRY(c, hipMalloc(&c->dIQ4, iQ4.size() * 4));
+            HIP_TRY(c, hipMemcpy(c->dIQ4, iQ4.data(), iQ4.size() * 4, hipMemcpyHostToDevice));
+            HIP_TRY(c, hipMalloc(&c->dILeafBox, iLeafBox.size() * 4));
+            HIP_TRY(c, hipMemcpy(c->dILeafBox, iLeafBox.data(), iLeafBox.size() * 4, hipMemcpyHostToDevice));
+        }
     }
     if (!wF.empty()) {
         HIP_TRY(c, hipMalloc(&c->dWF, wF.size() * sizeof(float)));

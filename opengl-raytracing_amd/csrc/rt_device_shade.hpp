@@ -37,6 +37,9 @@ struct DevScene {
     const float4 *iN2;       // implicit two-child records (round 5): 3 x float4 per inner node [Lmin.xyz Lmax.x][Lmax.yz Rmin.xy][Rmin.z Rmax.xyz] at d - popcount(p) + (p << (implD - d)); null unless every leaf sits at depth implD
     const float4 *iPairs;    // `pairs` in leaf order: leaf p owns the records from p * implR on, the spare word of the first holds the leaf's triangle count
     int implD, implR;
+    const float4 *iN4;       // implicit four-wide any-hit records: 6 x float4 per even-depth inner node [min.x x4][min.y][min.z][max.x][max.y][max.z] at the node's pre-order position
+    const float4 *iQ4;       // the same quantised: 3 x float4 [origin.xyz, exponents][lo.x lo.y lo.z hi.x][hi.y hi.z - -] (null: the exact form is walked)
+    const float4 *iLeafBox;  // with iQ4: 2 x float4 per leaf, its exact box, at the leaf's ordinal
     const float4 *pairs;     // 5 x float4 per PAIR of triangles of a leaf: [v0 e1 e2][v0 e1 e2][index of the first][-], see rt_upload_bvh
     const float4 *tris;
     const uchar4 *env;

@@ -539,8 +539,11 @@ extern __shared__ __align__(16) unsigned char rt_dyn_lds[];
 #ifndef RT_ANYHIT_WAVES
 #define RT_ANYHIT_WAVES 7   // any-hit launches: 72 VGPRs, seven waves per SIMD (with the exact stack size of rt_upload_bvh seven workgroups fit a CU's LDS)
 #endif
+#ifndef RT_IMPL_ANYHIT_WAVES
+#define RT_IMPL_ANYHIT_WAVES 6   // the implicit any-hit build at six waves per SIMD: at seven (72 VGPRs) it spills 32 B per lane into its inner loop (experiment 9)
+#endif
 template <class Src, bool ANY, int LEAFB, bool STATS = false, bool COOP = false, bool NEAR = false, int QN = 0, bool FUSE = false, bool IMPL = false>
-__global__ __launch_bounds__(256, (!STATS && !ANY) ? 5 : ((NEAR || QN == 2) ? 6 : (ANY && !STATS && LEAFB == 2 ? RT_ANYHIT_WAVES : 1))) void k_trace(const DevFrame *__restrict__ fr, const float4 *__restrict__ wnodes, const float4 *__restrict__ tris, Src src,
+__global__ __launch_bounds__(256, (!STATS && !ANY) ? 5 : ((NEAR || QN == 2 || (IMPL && RT_IMPL_ANYHIT_WAVES == 6)) ? 6 : (ANY && !STATS && LEAFB == 2 ? RT_ANYHIT_WAVES : 1))) void k_trace(const DevFrame *__restrict__ fr, const float4 *__restrict__ wnodes, const float4 *__restrict__ tris, Src src,
                                                 uint32_t *head, unsigned long long *tally, unsigned long long *gatherLoads, TraceTune tune,
                                                 int stackEntries, unsigned long long *stats = nullptr, const float4 *__restrict__ leafBox = nullptr) {
     // STATS (diagnostic build only, RT_TRACE_STATS=1): [0] inner-node visits [1] leaf visits [2] triangle tests [3] inner-phase wave
@@ -773,13 +776,30 @@ __global__ __launch_bounds__(256, (!STATS && !ANY) ? 5 : ((NEAR || QN == 2) ? 6 
                     int r0, r1, r2, r3;
                     float t0, t1, t2, t3;
                     bool h0, h1, h2, h3;
+                    // IMPL (RT_IMPLICIT=1, trees whose leaves sit at one depth D): `ref` = depth << 24 | path of an even-depth node; its children are (d + 2, 4p + j) -- leaves
+                    // -(4p + j + 1) when d + 2 == D, the two leaves -(2p + j + 1) when d + 1 == D -- so the record carries no references: six loads instead of seven
+                    // (quantised: three instead of four), at the node's pre-order position
+                    uint32_t dN = 0, pN = 0, atN = 0;
+                    auto impl_refs = [&]() {
+                        const uint32_t D = (uint32_t)sc.implD;
+                        if (dN + 1u == D) { r0 = -(int)(2u * pN + 1u); r1 = -(int)(2u * pN + 2u); r2 = RT_NO_CHILD; r3 = RT_NO_CHILD; }
+                        else if (dN + 2u == D) { r0 = -(int)(4u * pN + 1u); r1 = -(int)(4u * pN + 2u); r2 = -(int)(4u * pN + 3u); r3 = -(int)(4u * pN + 4u); }
+                        else { const int b = (int)(((dN + 2u) << 24) | (4u * pN)); r0 = b; r1 = b + 1; r2 = b + 2; r3 = b + 3; }
+                    };
+                    if constexpr (IMPL) {
+                        dN = (uint32_t)ref >> 24; pN = (uint32_t)ref & 0x00ffffffu;
+                        atN = dN - (uint32_t)__popc(pN) + (pN << ((uint32_t)sc.implD - dN));
+                        gathers -= 1u;      // (one load fewer than counted above)
+                    }
                     if constexpr (QN) {
                         // RT_QNODES: 64-byte node, child boxes as bytes on the node's own grid (rt_upload_bvh): box = fmaf(byte, 2^e, origin) per component,
                         // checked at upload to contain the child's box; then the slab test of the exact kernel on the decoded floats
-                        const v4f *ndv = reinterpret_cast<const v4f *>(nodes + (size_t)ref * 4);
-                        v4f p0 = ndv[0], p1 = ndv[1], p2 = ndv[2], p3 = ndv[3];
+                        const v4f *ndv = IMPL ? reinterpret_cast<const v4f *>(nodes) + (size_t)atN * 3 : reinterpret_cast<const v4f *>(nodes + (size_t)ref * 4);
+                        v4f p0 = ndv[0], p1 = ndv[1], p2 = ndv[2], p3 = {0, 0, 0, 0};
+                        if constexpr (!IMPL) p3 = ndv[3];
                         pin(p0); pin(p1); pin(p2); pin(p3);
-                        r0 = (int)f2u(p3.x); r1 = (int)f2u(p3.y); r2 = (int)f2u(p3.z); r3 = (int)f2u(p3.w);
+                        if constexpr (IMPL) impl_refs();
+                        else { r0 = (int)f2u(p3.x); r1 = (int)f2u(p3.y); r2 = (int)f2u(p3.z); r3 = (int)f2u(p3.w); }
                         const uint32_t ex = f2u(p0.w);
                         const float sx = u2f((ex & 0xffu) << 23), sy = u2f(((ex >> 8) & 0xffu) << 23), sz = u2f(((ex >> 16) & 0xffu) << 23);
                         const uint32_t lx = f2u(p1.x), ly = f2u(p1.y), lz = f2u(p1.z), hx = f2u(p1.w), hy = f2u(p2.x), hz = f2u(p2.y);
@@ -796,12 +816,13 @@ __global__ __launch_bounds__(256, (!STATS && !ANY) ? 5 : ((NEAR || QN == 2) ? 6 
                         h3 = box(3, t3) && r3 != RT_NO_CHILD;
                     } else {
                     // 4-wide node: up to four grandchild boxes per 128-byte record, order irrelevant for any-hit
-                    const float4 *nd = nodes + (size_t)ref * 8;
                     // component-wise: [min.x x4][min.y x4][min.z x4][max.x x4][max.y x4][max.z x4][ref x4] = 7 loads, 8th piece unused
-                    const v4f *ndv = reinterpret_cast<const v4f *>(nd);
-                    v4f q0 = ndv[0], q1 = ndv[1], q2 = ndv[2], q3 = ndv[3], q4 = ndv[4], q5 = ndv[5], q6 = ndv[6];
+                    const v4f *ndv = IMPL ? reinterpret_cast<const v4f *>(nodes) + (size_t)atN * 6 : reinterpret_cast<const v4f *>(nodes + (size_t)ref * 8);
+                    v4f q0 = ndv[0], q1 = ndv[1], q2 = ndv[2], q3 = ndv[3], q4 = ndv[4], q5 = ndv[5], q6 = {0, 0, 0, 0};
+                    if constexpr (!IMPL) q6 = ndv[6];
                     pin(q0); pin(q1); pin(q2); pin(q3); pin(q4); pin(q5); pin(q6);
-                    r0 = (int)f2u(q6.x); r1 = (int)f2u(q6.y); r2 = (int)f2u(q6.z); r3 = (int)f2u(q6.w);
+                    if constexpr (IMPL) impl_refs();
+                    else { r0 = (int)f2u(q6.x); r1 = (int)f2u(q6.y); r2 = (int)f2u(q6.z); r3 = (int)f2u(q6.w); }
                     h0 = slab(ro, rdInv, mk3(q0.x, q1.x, q2.x), mk3(q3.x, q4.x, q5.x), t0) && t0 <= tBest;
                     h1 = slab(ro, rdInv, mk3(q0.y, q1.y, q2.y), mk3(q3.y, q4.y, q5.y), t1) && t1 <= tBest;
                     // absent children carry NaN boxes: with v_min/v_max NaN semantics their slab test is false, so all
@@ -961,7 +982,7 @@ __global__ __launch_bounds__(256, (!STATS && !ANY) ? 5 : ((NEAR || QN == 2) ? 6 
             bool boxOK = true;
             v4f lb0 = {0, 0, 0, 0}, lb1 = lb0;
             if constexpr (QN) {
-                const uint32_t at = sc.leafBoxMagic ? __umulhi((uint32_t)first, sc.leafBoxMagic) : (uint32_t)first;
+                const uint32_t at = IMPL ? (uint32_t)v : (sc.leafBoxMagic ? __umulhi((uint32_t)first, sc.leafBoxMagic) : (uint32_t)first);   // implicit records: the leaf's ordinal
                 const v4f *lb = reinterpret_cast<const v4f *>(leafBox) + (size_t)at * 2;
                 lb0 = lb[0]; lb1 = lb[1];
                 gathers += 2u;
@@ -1015,12 +1036,13 @@ __global__ __launch_bounds__(256, (!STATS && !ANY) ? 5 : ((NEAR || QN == 2) ? 6 
                 pin(r0); pin(r1); pin(r2); pin(r3); pin(r4);
                 count = (int)f2u(r4.w);
                 if (STATS) st_[2] += (unsigned long long)min(count, 2);
+                if (QN) gate();                            // quantised nodes: the leaf's exact box, fetched with this record, decides whether its triangles count
                 float tt;
-                if (tri_hit(ro, rd, mk3(r0.x, r0.y, r0.z), mk3(r0.w, r1.x, r1.y), mk3(r1.z, r1.w, r2.x), eps, tBest, tt)) {
+                if (boxOK && tri_hit(ro, rd, mk3(r0.x, r0.y, r0.z), mk3(r0.w, r1.x, r1.y), mk3(r1.z, r1.w, r2.x), eps, tBest, tt)) {
                     if (ANY) done = true;
                     else { tBest = tt; triBest = (int)f2u(r4.z); }
                 }
-                if (!done && count >= 2 && tri_hit(ro, rd, mk3(r2.y, r2.z, r2.w), mk3(r3.x, r3.y, r3.z), mk3(r3.w, r4.x, r4.y), eps, tBest, tt)) {
+                if (boxOK && !done && count >= 2 && tri_hit(ro, rd, mk3(r2.y, r2.z, r2.w), mk3(r3.x, r3.y, r3.z), mk3(r3.w, r4.x, r4.y), eps, tBest, tt)) {
                     if (ANY) done = true;
                     else { tBest = tt; triBest = (int)f2u(r4.z) + 1; }
                 }
@@ -1571,9 +1593,11 @@ void launch_trace(hipStream_t st, int cus, int gridPct, int depth, const DevFram
     const size_t ldsBytes = (size_t)256 * stack * (ANY ? 4 : 8);
     const bool qn = ANY && tune.qnodes != 0 && hs.q4 != nullptr && !stats && !tune.nearFirst;   // (the diagnostic and near-first builds walk the exact nodes)   // -1: whenever rt_upload_bvh built the quantised nodes (trees beyond the L2)
     const bool fuse = !ANY && tune.fused != 0 && hs.wF != nullptr && !tune.coop;   // closest-hit launches: the fused records when rt_upload_bvh built them
-    const bool impl = !ANY && !fuse && tune.impl != 0 && hs.iN2 != nullptr && !tune.coop;   // ... the implicit records when every leaf sits at one depth
-    const float4 *nodes = ANY ? (qn ? hs.q4 : hs.w4) : (fuse ? hs.wF : (impl ? hs.iN2 : hs.wnodesW));
+    const bool impl = tune.impl != 0 && !stats && (ANY ? (hs.iN4 != nullptr && (!qn || hs.iQ4 != nullptr) && !tune.nearFirst && tune.leafb < 4 && !(qn && tune.qnodes == 1) && hs.anyStack > 0)
+                                                       : (!fuse && hs.iN2 != nullptr && !tune.coop));   // ... the implicit records when every leaf sits at one depth
+    const float4 *nodes = ANY ? (impl ? (qn ? hs.iQ4 : hs.iN4) : (qn ? hs.q4 : hs.w4)) : (fuse ? hs.wF : (impl ? hs.iN2 : hs.wnodesW));
     const float4 *pairRecords = impl ? hs.iPairs : hs.pairs;
+    const float4 *leafBoxes = (ANY && impl) ? hs.iLeafBox : hs.leafBox;
     auto go = [&](auto kernel) {
         // the runtime's answer per (device, kernel, LDS bytes): a process may hold contexts on devices of different shapes
         thread_local std::map<std::tuple<int, const void *, size_t>, int> occ;
@@ -1585,11 +1609,11 @@ void launch_trace(hipStream_t st, int cus, int gridPct, int depth, const DevFram
             perCU = std::min(perCU, 8);
         }
         const unsigned blocks = (unsigned)std::max(8, cus * perCU * gridPct / 100);
-        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), ldsBytes, st, fr, nodes, pairRecords, src, head, tally, gatherLoads, tune, stack, stats, hs.leafBox);
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), ldsBytes, st, fr, nodes, pairRecords, src, head, tally, gatherLoads, tune, stack, stats, leafBoxes);
     };
     const int leafb = ANY ? tune.leafb : tune.leafbClosest;
-    if (stats && impl) go(k_trace<Src, ANY, 2, true, false, false, 0, false, !ANY>);
-    else if (impl) go(k_trace<Src, ANY, 2, false, false, false, 0, false, !ANY>);
+    if (impl && ANY) { if (qn) go(k_trace<Src, ANY, 2, false, false, false, ANY ? 2 : 0, false, true>); else go(k_trace<Src, ANY, 2, false, false, false, 0, false, true>); }
+    else if (impl) go(k_trace<Src, ANY, 2, false, false, false, 0, false, true>);
     else if (stats && fuse) go(k_trace<Src, ANY, 2, true, false, false, 0, !ANY>);
     else if (stats) { if (leafb >= 4) go(k_trace<Src, ANY, 4, true>); else go(k_trace<Src, ANY, 2, true>); }
     else if (fuse) go(k_trace<Src, ANY, 2, false, false, false, 0, !ANY>);

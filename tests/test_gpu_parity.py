@@ -101,7 +101,7 @@ def test_traversal_matches_oracle_ray_by_ray(ren, orc):
     assert np.array_equal(got[:, 0], want)
 
 
-@pytest.mark.parametrize("qn", [0, 2, "million", "fused", "implicit"])
+@pytest.mark.parametrize("qn", [0, 2, "million", "fused", "implicit", "implicit_q", "implicit_million"])
 def test_wavefront_traversal_kernels_ray_by_ray_on_adversarial_rays(orc, monkeypatch, qn):
     """rt_debug_trace kinds 2 / 3: arbitrary rays through the PRODUCTION traversal kernels (k_trace: persistent launch, refill scheduler, 4-wide any-hit
     nodes -- exact and, with RT_QNODES=2, quantised), answer by answer against the oracle's restatement of traceBVH / traceBVHShadow.  Besides random rays:
@@ -111,9 +111,11 @@ def test_wavefront_traversal_kernels_ray_by_ray_on_adversarial_rays(orc, monkeyp
     if qn == "fused":                   # round 5: the closest-hit launches on the fused records (RT_FUSED=1: the reference's order, two binary steps per round trip)
         monkeypatch.setenv("RT_FUSED", "1")
         qn = 0
-    if qn == "implicit":                # round 5: the closest-hit launches on 48-byte records without child references (RT_IMPLICIT=1; the mesh's leaves all sit at depth 10)
+    if qn in ("implicit", "implicit_q", "implicit_million"):
+        # round 5, RT_IMPLICIT=1: records without child references (the mesh's leaves all sit at depth 10; the 1 M-triangle scene's at depth 17) -- 48 bytes for the
+        # closest-hit launches, 96 bytes for the any-hit launches, 48 bytes for their quantised form (implicit_q: forced on; implicit_million: chosen by size)
         monkeypatch.setenv("RT_IMPLICIT", "1")
-        qn = 0
+        qn = {"implicit": 0, "implicit_q": 2, "implicit_million": "million"}[qn]
     if qn == "million":                 # the 1 M-triangle scene with the form rt_upload_bvh chooses for it by itself (quantised: 9.8 MB of exact nodes)
         monkeypatch.delenv("RT_QNODES", raising=False)
         v_, f_ = rt.meshgen.million_triangle_scene()
@@ -317,23 +319,27 @@ def test_quantised_anyhit_nodes(orc, monkeypatch, qn, mesh, sah):
             prev = want[0]
 
 
-@pytest.mark.parametrize("mesh", ["one_leaf", "tiny", "deep", "ragged", "odd_counts"])
+@pytest.mark.parametrize("mesh", ["one_leaf", "tiny", "deep", "ragged", "odd_counts", "deep_q", "odd_depth", "odd_depth_q"])
 def test_implicit_closest_hit_records(orc, monkeypatch, mesh):
     """RT_IMPLICIT=1 (round 5, a measured option): when every leaf of the uploaded tree sits at one depth D a node is named by (depth, path), its children and
     the leaves' triangle records follow by arithmetic, and the closest-hit launches read 48-byte records -- the two child boxes, three loads -- instead of 64-byte
-    ones.  Same boxes, order and triangle tests, hence the same frames: a single leaf (nothing to do), a one-level tree, a depth-10 tree, a mesh whose leaves
+    ones; the any-hit launches read 96-byte four-child records (six loads instead of seven) or, quantised, 48-byte ones (three instead of four).  Same boxes, order and triangle tests, hence the same frames: a single leaf (nothing to do), a one-level tree, a depth-10 tree, a mesh whose leaves
     sit at two depths (rt_upload_bvh must say so and the option fall back to the explicit records), and a perfect tree whose leaves hold 5 or 6 triangles (the
     count travels in the leaf's first record)."""
     monkeypatch.setenv("RT_IMPLICIT", "1")
+    if mesh.endswith("_q"):                # the any-hit launches on the quantised form of the implicit records (three loads per node visit)
+        monkeypatch.setenv("RT_QNODES", "2")
+        mesh = mesh[:-2]
     W, H = 96, 64
     rng = np.random.default_rng(3)
     if mesh == "one_leaf":
         tris9 = np.array([[-1, 0, -1, 1, 0, -1, 0, 1.5, -1.2], [-1, 0, 1, 1, 0, 1, 0, 1.5, 0.5]], np.float32) + np.float32(0.25)
         nodes, tris = rt.build_bvh(tris9)
-    elif mesh in ("ragged", "odd_counts"):
+    elif mesh in ("ragged", "odd_counts", "odd_depth"):
         # random small triangles around the close-up camera's target: 1100 of them split into leaves at depths 7 and 8 (1100 / 2^7 = 8.6), 1400 into a perfect
-        # depth-8 tree with five or six triangles per leaf (1400 / 2^8 = 5.5)
-        n = 1100 if mesh == "ragged" else 1400
+        # depth-8 tree with five or six triangles per leaf (1400 / 2^8 = 5.5), 700 into a perfect depth-7 tree (an ODD depth: the last four-wide nodes of the
+        # any-hit walk hold two leaves and two absent children)
+        n = {"ragged": 1100, "odd_counts": 1400, "odd_depth": 700}[mesh]
         c = (np.array([-2.0, 1.5, 0.0]) + rng.uniform(-0.5, 0.5, (n, 3))).astype(np.float32)
         tris9 = np.concatenate([c, c + rng.uniform(-0.08, 0.08, (n, 3)).astype(np.float32), c + rng.uniform(-0.08, 0.08, (n, 3)).astype(np.float32)], axis=1).astype(np.float32)
         nodes, tris = rt.build_bvh(tris9)
@@ -347,7 +353,9 @@ def test_implicit_closest_hit_records(orc, monkeypatch, mesh):
         r.upload_bvh(nodes, tris)
         info = r.scene_info()
         implicit = bool(info.flags & rt.RT_SCENE_IMPLICIT)
-        assert implicit == (mesh in ("tiny", "deep", "odd_counts")), (mesh, info.flags, info.implicitDepth)
+        assert implicit == (mesh in ("tiny", "deep", "odd_counts", "odd_depth")), (mesh, info.flags, info.implicitDepth)
+        if mesh == "odd_depth":
+            assert info.implicitDepth == 7
         if mesh == "deep":
             assert info.implicitDepth == 10
         r.upload_env(faces)

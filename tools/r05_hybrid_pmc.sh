@@ -17,5 +17,5 @@ SETS=(
 for i in ${!SETS[@]}; do
   timeout -k 10 200 rocprofv3 --pmc ${SETS[$i]} --output-format csv -d $OUT/p$i -- python3 $R/bench.py $ARGS > $OUT/p$i.log 2>&1 || { echo "pass $i failed"; tail -2 $OUT/p$i.log; }
 done
-python3 $R/tools/pmc_sum.py $OUT 2>/dev/null | grep -A2 "hybrid_shade\|hybrid_verify" | cut -c1-2500 | tee $OUT/summary.txt
+python3 $R/tools/pmc_sum.py $OUT 2>/dev/null | grep -A2 "hybrid_shade\|hybrid_verify\|k_trace" | cut -c1-2500 | tee $OUT/summary.txt
 rm -rf $OUT/p*/
