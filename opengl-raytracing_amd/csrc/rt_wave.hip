@@ -486,13 +486,14 @@ RT_DEV uint32_t quad_distinct(uint32_t key) {
 constexpr uint32_t kShards = 64, kShardStride = 32;   // cursor shards per trace launch, uint32 words between them (128 B)
 constexpr uint32_t kHeadWords = kShards * kShardStride;
 
-struct TraceTune { int refillMin; int minSearch; int chunk; int leafb; int skipTraversal; int quadRefill; int coop; int leafbClosest; int nearFirst; int reverse; int guided; int chunkMax; int denseTake; int qnodes; int fused; int impl; };   // skipTraversal: diagnostic (RT_DEBUG_SKIP_TRAVERSAL)
+struct TraceTune { int refillMin; int minSearch; int chunk; int leafb; int skipTraversal; int quadRefill; int coop; int leafbClosest; int nearFirst; int reverse; int guided; int chunkMax; int denseTake; int qnodes; int fused; int impl; int timing; };   // skipTraversal: diagnostic (RT_DEBUG_SKIP_TRAVERSAL)
 // fused (RT_FUSED=1, measured option of round 5, off): closest-hit launches walk the fused records (DevScene::wF) when rt_upload_bvh built them -- the reference's
 // visiting order in half the dependent round trips (bounce rays: 20.6 -> 11.2 steps, primary 17.1 -> 9.7), bit-identical, and 3-4 % SLOWER in every mode (batched,
 // frame by frame, one rank of eight): the same number of 16-byte lane-loads per ray, and that number -- not the length of the dependency chain -- is what these
 // launches cost (profiles/r05_experiments.txt 1)
 static TraceTune default_tune() {
-    TraceTune t{32, 16, 0, 2, 0, 0, 0, 2, 0, 1, 0, 768, 1, -1, 0, 0};
+    TraceTune t{32, 16, 0, 2, 0, 0, 0, 2, 0, 1, 0, 768, 1, -1, 0, 0, 0};
+    if (const char *e = getenv("RT_TRACE_TIMING")) t.timing = atoi(e);
     // impl (RT_IMPLICIT=1, measured option of round 5, off): closest-hit launches walk 48-byte records WITHOUT child references (three loads per node visit instead of
     // four) when every leaf of the tree sits at one depth (rt_upload_bvh) -- bit-identical, 25 % fewer node loads, and no faster (bounce launch 0.615 -> 0.628 ms per
     // frame, primary 0.253 -> 0.259): together with `fused` the second half of the finding that neither the loads nor the dependent steps of these launches can be
@@ -542,7 +543,7 @@ extern __shared__ __align__(16) unsigned char rt_dyn_lds[];
 #ifndef RT_IMPL_ANYHIT_WAVES
 #define RT_IMPL_ANYHIT_WAVES 6   // the implicit any-hit build at six waves per SIMD: at seven (72 VGPRs) it spills 32 B per lane into its inner loop (experiment 9)
 #endif
-template <class Src, bool ANY, int LEAFB, bool STATS = false, bool COOP = false, bool NEAR = false, int QN = 0, bool FUSE = false, bool IMPL = false>
+template <class Src, bool ANY, int LEAFB, bool STATS = false, bool COOP = false, bool NEAR = false, int QN = 0, bool FUSE = false, bool IMPL = false, bool TIMING = false>
 __global__ __launch_bounds__(256, (!STATS && !ANY) ? 5 : ((NEAR || QN == 2 || (IMPL && RT_IMPL_ANYHIT_WAVES == 6)) ? 6 : (ANY && !STATS && LEAFB == 2 ? RT_ANYHIT_WAVES : 1))) void k_trace(const DevFrame *__restrict__ fr, const float4 *__restrict__ wnodes, const float4 *__restrict__ tris, Src src,
                                                 uint32_t *head, unsigned long long *tally, unsigned long long *gatherLoads, TraceTune tune,
                                                 int stackEntries, unsigned long long *stats = nullptr, const float4 *__restrict__ leafBox = nullptr) {
@@ -551,7 +552,16 @@ __global__ __launch_bounds__(256, (!STATS && !ANY) ? 5 : ((NEAR || QN == 2 || (I
     unsigned long long st_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // [14] / [15]: the same with wave-wide merging (distinct records per wave step)   // [8] cycles in inner steps [9] in leaf phases [10] in refills [11] wave lifetime
     // [12] / [13] node / triangle gather loads after merging: adjacent lanes (a quad) that stand on the same record read the same 16-byte
     // pieces, which the vector L1 serves as one access (quad_distinct above) -- (quad, record) pairs per wave step x loads per record
-    const unsigned long long tStart_ = STATS ? clock64() : 0ull;
+    const unsigned long long tStart_ = (STATS || TIMING) ? clock64() : 0ull;
+    // TIMING (RT_TRACE_TIMING=1, diagnostic build of the PRODUCTION kernels -- same registers and occupancy, nothing of the STATS build's counting): where a wave's cycles
+    // go, from s_memtime stamps kept in scalar registers: [0] inner-phase iterations [1] cycles from the top of an iteration to the issue of its loads [2] from there to
+    // their arrival (an explicit s_waitcnt vmcnt(0)) [3] from there to the end of the iteration [4] leaf phases [5] cycles in them [6] refill rounds [7] cycles in them
+    // [8] wave lifetime
+    unsigned long long tm_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tA_ = 0, tB_ = 0, tC_ = 0;
+    auto stamp_loads = [&]() {
+        if constexpr (TIMING) { tB_ = clock64(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tC_ = clock64(); }
+    };
     typedef typename StackOf<ANY>::type Entry;
     Entry *stk = reinterpret_cast<Entry *>(rt_dyn_lds) + (threadIdx.x >> 6) * stackEntries * 64 + (threadIdx.x & 63);
     DevScene sc = fr->sc;   // private copy: scene constants stay in SGPRs instead of being re-read per step
@@ -640,7 +650,7 @@ __global__ __launch_bounds__(256, (!STATS && !ANY) ? 5 : ((NEAR || QN == 2 || (I
         unsigned long long idleMask = whole_quads(__ballot(!active));
         int nIdle = __popcll(idleMask);
         if (!exhausted && nIdle >= tune.refillMin) {
-            const unsigned long long tR_ = STATS ? clock64() : 0ull;
+            const unsigned long long tR_ = (STATS || TIMING) ? clock64() : 0ull;
             if (STATS && lane == 0) st_[7]++;
             if (runNext >= runEnd) {
                 // shard s owns runs s, s + kShards, ...: k = 0 .. runsOf(s)-1
@@ -741,6 +751,7 @@ __global__ __launch_bounds__(256, (!STATS && !ANY) ? 5 : ((NEAR || QN == 2 || (I
                 idleLeft = whole_quads(__ballot(!active));                     // root misses may draw again
             }
             if (STATS && lane == 0) st_[10] += clock64() - tR_;
+            if constexpr (TIMING) { tm_[6]++; tm_[7] += clock64() - tR_; }
             continue;   // lanes that drew a dead slot or a root miss may draw again
         }
         if (__ballot(active) == 0ull) {
@@ -754,6 +765,7 @@ __global__ __launch_bounds__(256, (!STATS && !ANY) ? 5 : ((NEAR || QN == 2 || (I
             if (sm == 0ull) break;
             if (__popcll(sm) < tune.minSearch && __ballot(active && (ANY ? leaf != 0 : ref < 0)) != 0ull) break;   // keep the leaf phase dense
             const unsigned long long tI_ = STATS ? clock64() : 0ull;
+            if constexpr (TIMING) { tA_ = clock64(); tB_ = tC_ = 0; }
             if (STATS && lane == 0) { st_[3]++; st_[4] += (unsigned long long)__popcll(sm); }
             // COOP (closest-hit, RT_COOP=1): the quad fetches its searching lanes' records together, then transposes (see quad_transpose)
             v4f ca = {0, 0, 0, 0}, cb = ca, cc = ca, cd = ca;
@@ -821,6 +833,7 @@ __global__ __launch_bounds__(256, (!STATS && !ANY) ? 5 : ((NEAR || QN == 2 || (I
                     v4f q0 = ndv[0], q1 = ndv[1], q2 = ndv[2], q3 = ndv[3], q4 = ndv[4], q5 = ndv[5], q6 = {0, 0, 0, 0};
                     if constexpr (!IMPL) q6 = ndv[6];
                     pin(q0); pin(q1); pin(q2); pin(q3); pin(q4); pin(q5); pin(q6);
+                    stamp_loads();
                     if constexpr (IMPL) impl_refs();
                     else { r0 = (int)f2u(q6.x); r1 = (int)f2u(q6.y); r2 = (int)f2u(q6.z); r3 = (int)f2u(q6.w); }
                     h0 = slab(ro, rdInv, mk3(q0.x, q1.x, q2.x), mk3(q3.x, q4.x, q5.x), t0) && t0 <= tBest;
@@ -868,6 +881,7 @@ __global__ __launch_bounds__(256, (!STATS && !ANY) ? 5 : ((NEAR || QN == 2 || (I
                     const v4f *ndv = reinterpret_cast<const v4f *>(nodes) + (size_t)at * 3;
                     v4f a = ndv[0], b = ndv[1], c = ndv[2];
                     pin(a); pin(b); pin(c);
+                    stamp_loads();
                     gathers -= 1u;                                              // (4 were counted above)
                     float tL, tR;
                     const bool hitL = slab(ro, rdInv, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), tL) && tL <= tBest;
@@ -948,7 +962,7 @@ __global__ __launch_bounds__(256, (!STATS && !ANY) ? 5 : ((NEAR || QN == 2 || (I
                     const v4f *ndv = reinterpret_cast<const v4f *>(nd);
                     v4f a, b, c, d;
                     if constexpr (COOP) { a = ca; b = cb; c = cc; d = cd; }
-                    else { a = ndv[0]; b = ndv[1]; c = ndv[2]; d = ndv[3]; pin(a); pin(b); pin(c); pin(d); }
+                    else { a = ndv[0]; b = ndv[1]; c = ndv[2]; d = ndv[3]; pin(a); pin(b); pin(c); pin(d); stamp_loads(); }
                     float tL, tR;
                     bool hitL = slab(ro, rdInv, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), tL) && tL <= tBest;
                     bool hitR = slab(ro, rdInv, mk3(c.x, c.y, c.z), mk3(d.x, d.y, d.z), tR) && tR <= tBest;
@@ -967,9 +981,10 @@ __global__ __launch_bounds__(256, (!STATS && !ANY) ? 5 : ((NEAR || QN == 2 || (I
                 }
             }
             if (STATS) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (lane == 0) st_[8] += clock64() - tI_; }
+            if constexpr (TIMING) { const unsigned long long tD = clock64(); tm_[0]++; if (tB_) { tm_[1] += tB_ - tA_; tm_[2] += tC_ - tB_; tm_[3] += tD - tC_; } }
         }
         // ---- phase 2: leaves
-        const unsigned long long tL_ = STATS ? clock64() : 0ull;
+        const unsigned long long tL_ = (STATS || TIMING) ? clock64() : 0ull;
         const int leafNow = ANY ? leaf : ref;   // any-hit: the postponed leaf; closest: the leaf the walk stopped at
         if (STATS) { unsigned long long lm = __ballot(active && leafNow < 0); if (lane == 0 && lm) { st_[5]++; st_[6] += (unsigned long long)__popcll(lm); } }
         if (active && leafNow < 0) {
@@ -1078,8 +1093,10 @@ __global__ __launch_bounds__(256, (!STATS && !ANY) ? 5 : ((NEAR || QN == 2 || (I
             } else pop_or_finish();
         }
         if (STATS && lane == 0) st_[9] += clock64() - tL_;
+        if constexpr (TIMING) { tm_[4]++; tm_[5] += clock64() - tL_; }
     }
     if (STATS && lane == 0) st_[11] = clock64() - tStart_;
+    if constexpr (TIMING) { tm_[8] = clock64() - tStart_; if (stats && lane == 0) for (int q = 0; q < 9; ++q) atomicAdd(&stats[q], tm_[q]); }
     if (STATS && stats) {
         for (int q = 0; q < 16; ++q) {
             unsigned long long v = st_[q];
@@ -1593,7 +1610,7 @@ void launch_trace(hipStream_t st, int cus, int gridPct, int depth, const DevFram
     const size_t ldsBytes = (size_t)256 * stack * (ANY ? 4 : 8);
     const bool qn = ANY && tune.qnodes != 0 && hs.q4 != nullptr && !stats && !tune.nearFirst;   // (the diagnostic and near-first builds walk the exact nodes)   // -1: whenever rt_upload_bvh built the quantised nodes (trees beyond the L2)
     const bool fuse = !ANY && tune.fused != 0 && hs.wF != nullptr && !tune.coop;   // closest-hit launches: the fused records when rt_upload_bvh built them
-    const bool impl = tune.impl != 0 && !stats && (ANY ? (hs.iN4 != nullptr && (!qn || hs.iQ4 != nullptr) && !tune.nearFirst && tune.leafb < 4 && !(qn && tune.qnodes == 1) && hs.anyStack > 0)
+    const bool impl = tune.impl != 0 && (!stats || tune.timing) && (ANY ? (hs.iN4 != nullptr && (!qn || hs.iQ4 != nullptr) && !tune.nearFirst && tune.leafb < 4 && !(qn && tune.qnodes == 1) && hs.anyStack > 0)
                                                        : (!fuse && hs.iN2 != nullptr && !tune.coop));   // ... the implicit records when every leaf sits at one depth
     const float4 *nodes = ANY ? (impl ? (qn ? hs.iQ4 : hs.iN4) : (qn ? hs.q4 : hs.w4)) : (fuse ? hs.wF : (impl ? hs.iN2 : hs.wnodesW));
     const float4 *pairRecords = impl ? hs.iPairs : hs.pairs;
@@ -1612,6 +1629,10 @@ void launch_trace(hipStream_t st, int cus, int gridPct, int depth, const DevFram
         hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), ldsBytes, st, fr, nodes, pairRecords, src, head, tally, gatherLoads, tune, stack, stats, leafBoxes);
     };
     const int leafb = ANY ? tune.leafb : tune.leafbClosest;
+    if (stats && tune.timing) {   // RT_TRACE_TIMING=1: the production kernel of this launch with scalar time stamps (exact / implicit records, default leaf groups only)
+        if (impl) go(k_trace<Src, ANY, 2, false, false, false, 0, false, true, true>); else go(k_trace<Src, ANY, 2, false, false, false, 0, false, false, true>);
+        return;
+    }
     if (impl && ANY) { if (qn) go(k_trace<Src, ANY, 2, false, false, false, ANY ? 2 : 0, false, true>); else go(k_trace<Src, ANY, 2, false, false, false, 0, false, true>); }
     else if (impl) go(k_trace<Src, ANY, 2, false, false, false, 0, false, true>);
     else if (stats && fuse) go(k_trace<Src, ANY, 2, true, false, false, 0, !ANY>);
@@ -1894,7 +1915,7 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
     if (const char *e = getenv("RT_GRID_PCT")) gridPct = std::max(1, atoi(e));
     int gridPctPrimary = host.g.world > 1 ? gridPct : 100;
     if (const char *e = getenv("RT_GRID_PCT_PRIMARY")) gridPctPrimary = std::max(1, atoi(e));
-    if (getenv("RT_TRACE_STATS") && !w->stats) { W_TRY(hipMalloc(&w->stats, 64 * sizeof(unsigned long long))); W_TRY(hipMemset(w->stats, 0, 64 * sizeof(unsigned long long))); }
+    if ((getenv("RT_TRACE_STATS") || getenv("RT_TRACE_TIMING")) && !w->stats) { W_TRY(hipMalloc(&w->stats, 64 * sizeof(unsigned long long))); W_TRY(hipMemset(w->stats, 0, 64 * sizeof(unsigned long long))); }
     unsigned long long *S = w->stats;
     const TraceTune tune = w->tune;
     const unsigned tilesFrame = (unsigned)std::max(host.g.nLocalTiles, 0);
@@ -2066,6 +2087,22 @@ int rt_wave_traced(RtWave *w, hipStream_t st, unsigned long long *out8, bool res
         unsigned long long v[64];
         W_TRY(hipMemcpy(v, w->stats, sizeof v, hipMemcpyDeviceToHost));
         static const char *nm[4] = {"primary", "shadow", "bounce", "bounce_shadow"};
+        if (getenv("RT_TRACE_TIMING") && atoi(getenv("RT_TRACE_TIMING"))) {
+            // RT_TRACE_TIMING=1 (k_trace<.., TIMING>): sums over all waves of the launches since the last reset
+            for (int k = 0; k < 3; ++k) {
+                const unsigned long long *q = v + k * 16;
+                if (!q[0] && !q[4]) continue;
+                const double it = (double)std::max<unsigned long long>(q[0], 1), lf = (double)std::max<unsigned long long>(q[4], 1), rf = (double)std::max<unsigned long long>(q[6], 1);
+                fprintf(stderr, "[trace timing] %-8s wave lifetime %.4g cycles | inner iterations %.4g: to load issue %.0f + loads in flight %.0f + after arrival %.0f cycles each (%.2f / %.2f / %.2f of the "
+                                "lifetime) | leaf phases %.4g: %.0f cycles each (%.2f) | refill rounds %.4g: %.0f cycles each (%.2f)\n",
+                        nm[k], (double)q[8], it, q[1] / it, q[2] / it, q[3] / it, (double)q[1] / (double)std::max<unsigned long long>(q[8], 1), (double)q[2] / (double)std::max<unsigned long long>(q[8], 1),
+                        (double)q[3] / (double)std::max<unsigned long long>(q[8], 1), lf, q[5] / lf, (double)q[5] / (double)std::max<unsigned long long>(q[8], 1), rf, q[7] / rf,
+                        (double)q[7] / (double)std::max<unsigned long long>(q[8], 1));
+            }
+            if (reset) W_TRY(hipMemset(w->stats, 0, sizeof v));
+            if (reset) W_TRY(hipMemset(w->acc, 0, 16 * sizeof(unsigned long long)));
+            return RT_OK;
+        }
         const char *mode = getenv("RT_TRACE_STATS");
         const bool quiet = mode && atoi(mode) >= 2;   // RT_TRACE_STATS=2: collect (rt_get_traced_rays' mergedLoads*), do not print
         for (int k = 0; k < 4; ++k) {
