@@ -62,7 +62,10 @@ struct WaveBuf {
     float4 *giO, *giD;       // bounce queue: SPP slots x CH
     float *giT;
     int *giTri;
-    float4 *sh2O, *sh2D;     // shadow queue 2: 6 slots x (CH*SPP), entries compacted over the (hit, sample) pairs whose bounce hit
+    float4 *sh2O, *sh2D;     // shadow queue 2: 6 slots x q2Stride, entries compacted over the (hit, sample) pairs whose bounce hit
+    uint32_t q2Stride;       // entries per slot of queue 2: CH * SPP (every bounce ray may hit) for small launch sets; for large ones (round 5) a capacity PREDICTED from the bounce
+                             // hits of earlier batches -- a (hit, sample) pair whose entry lies beyond it is not queued: k_gen_gi_overflow traces its six rays in place
+    uint8_t *occOvf;         // answers of those rays, [6][CH * SPP] (per lane, like occ2)
     uint8_t *occ2;
     int *giPos;              // per (sample, hit): entry in queue 2, -1 when the bounce ray missed or was not cast
     int *giPerm;             // RT_BIN_GI=1 (experiment, round 4): per (sample, hit) the bounce queue entry its ray was sorted to; null = entry (sample, hit) itself
@@ -1432,7 +1435,8 @@ struct GenGiTracer {       // reads the bounce result, records the shadow rays a
     uint32_t shadowMask;
     RT_DEV bool shadow(int seg, int k, V3 ro, V3 rd, float tMax, bool matters) {
         if (seg != SEG_GI_DIRECT) return false;
-        uint32_t a = (uint32_t)k * (wb.CH * (uint32_t)wb.SPP) + pos;
+        if (pos >= wb.q2Stride) return false;          // beyond the queue's capacity: k_gen_gi_overflow traces this pair's rays itself
+        uint32_t a = (uint32_t)k * wb.q2Stride + pos;
         shadowMask |= 1u << k;
         if (!matters) { wb.sh2T[a] = -1.0f; return false; }
         wb.sh2T[a] = fmaxr(tMax, 0.0f);
@@ -1458,7 +1462,8 @@ struct CombineTracer {     // reads everything
     RT_DEV bool shadow(int seg, int k, V3, V3, float, bool matters) {
         if (!matters) return false;
         if (seg == SEG_DIRECT) return wb.occ1[wb.sh1_slot(k >= 4 ? 0 : s, k) * wb.CH + j] != 0;   // sun / point: sample 0's ray
-        return wb.occ2[(uint32_t)k * (wb.CH * (uint32_t)wb.SPP) + (uint32_t)wb.giPos[(uint32_t)s * wb.CH + j]] != 0;
+        const uint32_t gp = (uint32_t)wb.giPos[(uint32_t)s * wb.CH + j];
+        return (gp < wb.q2Stride ? wb.occ2[(uint32_t)k * wb.q2Stride + gp] : wb.occOvf[(uint32_t)k * (wb.CH * (uint32_t)wb.SPP) + gp]) != 0;
     }
     RT_DEV int gi(V3 ro, V3 rd, V3 &hp, V3 &hn) {
         uint32_t a = wb.gi_entry(s, j);
@@ -1563,8 +1568,57 @@ __global__ __launch_bounds__(256) void k_gen_gi(const DevFrame *__restrict__ fr,
     const int seed = (int)((uint32_t)c.F.frameIndex * (uint32_t)SPP + (uint32_t)s);
     Work w;
     (void)oneBounceGIBVH<GenGiTracer, false>(tr, c.F, c.hp, c.hn, c.F.frameIndex, seed, w);
-    for (int k = 0; k < 6; ++k)
-        if (!(tr.shadowMask & (1u << k))) wb.sh2T[(uint32_t)k * (wb.CH * (uint32_t)wb.SPP) + pos] = -1.0f;
+    if (pos < wb.q2Stride)
+        for (int k = 0; k < 6; ++k)
+            if (!(tr.shadowMask & (1u << k))) wb.sh2T[(uint32_t)k * wb.q2Stride + pos] = -1.0f;
+}
+
+// Shadow queue 2 of a large launch set holds a PREDICTED number of bounce hits (rt_wave_render).  The (hit, sample) pairs beyond it -- none, unless the view changed so
+// that more than twice as many bounce rays hit as in any batch before -- get their six shadow rays traced right here, one thread per pair, with the megakernel's any-hit
+// walk (bvh_anyhit: the same answers as the any-hit launch, tests/test_gpu_parity.py), into occOvf.  Launched behind every k_gen_gi of such a set; returns at once when
+// nothing overflowed.
+struct GenGiOverflowTracer {
+    WaveBuf wb;
+    const DevScene *sc;
+    float eps;
+    StackEntry *stk;
+    uint32_t j;
+    int s;
+    uint32_t pos;
+    RT_DEV bool shadow(int seg, int k, V3 ro, V3 rd, float tMax, bool matters) {
+        if (seg != SEG_GI_DIRECT) return false;
+        bool occ = false;
+        if (matters) { Work w; occ = bvh_anyhit<false>(*sc, ro, rd, eps, fmaxr(tMax, 0.0f), stk, w); }
+        wb.occOvf[(uint32_t)k * (wb.CH * (uint32_t)wb.SPP) + pos] = occ ? 1 : 0;
+        return false;
+    }
+    RT_DEV int gi(V3 ro, V3 rd, V3 &hp, V3 &hn) {
+        uint32_t a = wb.gi_entry(s, j);
+        int tri = wb.giTri[a];
+        if (tri < 0) return 0;
+        hp = ro + rd * wb.giT[a];
+        hn = tri_normal(*sc, tri);
+        return 1;
+    }
+    RT_DEV bool ao(int, V3, V3, float) { return false; }
+};
+__global__ __launch_bounds__(256) void k_gen_gi_overflow(const DevFrame *__restrict__ fr, WaveBuf wb, uint32_t c0, const uint32_t *giCount, int stackEntries) {
+    if (*giCount <= wb.q2Stride) return;
+    const uint32_t live = chunk_live(wb, c0);
+    const uint32_t tid = blockIdx.x * 256 + threadIdx.x;
+    if (live == 0 || tid >= live * (uint32_t)wb.SPP) return;
+    const int s = (int)(tid / live);
+    const uint32_t j = tid % live;
+    const int gp = wb.giPos[(uint32_t)s * wb.CH + j];
+    if (gp < 0 || (uint32_t)gp < wb.q2Stride) return;
+    GenGiOverflowTracer tr;
+    tr.wb = wb; tr.sc = &fr->sc; tr.eps = fr->u.eps; tr.j = j; tr.s = s; tr.pos = (uint32_t)gp;
+    tr.stk = reinterpret_cast<StackEntry *>(rt_dyn_lds) + (threadIdx.x >> 6) * stackEntries * 64 + (threadIdx.x & 63);
+    HitCtx c = load_hit(fr, wb.hits[c0 + j]);
+    const int SPP = max(fr->u.spp, 1);
+    const int seed = (int)((uint32_t)c.F.frameIndex * (uint32_t)SPP + (uint32_t)s);
+    Work w;
+    (void)oneBounceGIBVH<GenGiOverflowTracer, false>(tr, c.F, c.hp, c.hn, c.F.frameIndex, seed, w);
 }
 
 // ---- stage: combine (thread = hit) ---------------------------------------------------------------
@@ -1673,6 +1727,10 @@ struct RtArenaPool {
     int n = 0;
     void *mem[RT_MAX_LANES] = {};
     size_t bytes[RT_MAX_LANES] = {};
+    void *mem2[RT_MAX_LANES] = {};             // shadow queue 2 of the arena: its own allocation, sized -- for large launch sets -- from the bounce hits of earlier batches
+    double q2Frac = 0.0;                       // largest share of (hit, sample) pairs whose bounce ray hit, over the launch sets of all lanes so far (read back with the NEXT
+                                               // launch set's hit count: no extra synchronisation); 0: nothing known yet
+    size_t bytes2[RT_MAX_LANES] = {};
     hipEvent_t freeEv[RT_MAX_LANES] = {};      // recorded behind the last kernel of the batch that used the arena last
     hipStream_t lastUser[RT_MAX_LANES] = {};   // (a later batch on the same stream is ordered behind it anyway)
 };
@@ -1684,11 +1742,11 @@ RtArenaPool *rt_arena_pool_create(int arenas) {
 }
 void rt_arena_pool_destroy(RtArenaPool *p) {
     if (!p) return;
-    for (int i = 0; i < RT_MAX_LANES; ++i) { if (p->mem[i]) (void)hipFree(p->mem[i]); if (p->freeEv[i]) (void)hipEventDestroy(p->freeEv[i]); }
+    for (int i = 0; i < RT_MAX_LANES; ++i) { if (p->mem[i]) (void)hipFree(p->mem[i]); if (p->mem2[i]) (void)hipFree(p->mem2[i]); if (p->freeEv[i]) (void)hipEventDestroy(p->freeEv[i]); }
     delete p;
 }
 int rt_arena_pool_count(const RtArenaPool *p) { int c = 0; for (int i = 0; p && i < RT_MAX_LANES; ++i) c += p->mem[i] ? 1 : 0; return c; }
-size_t rt_arena_pool_bytes(const RtArenaPool *p) { size_t b = 0; for (int i = 0; p && i < RT_MAX_LANES; ++i) b += p->bytes[i]; return b; }
+size_t rt_arena_pool_bytes(const RtArenaPool *p) { size_t b = 0; for (int i = 0; p && i < RT_MAX_LANES; ++i) b += p->bytes[i] + p->bytes2[i]; return b; }
 
 struct RtWave {
     std::string err;
@@ -1703,6 +1761,10 @@ struct RtWave {
     // allocations
     size_t slotsCap = 0;      // per-frame arrays sized for this many pixel slots
     size_t chunkBytes = 0;    // bytes of the per-chunk arena
+    void *q2Arena = nullptr;  // shadow queue 2 (pool: the arena's mem2)
+    int prevChunks = 0, prevSPP = 1;   // chunks / spp of this lane's previous launch set: its hit count and bounce-hit counts are copied to hostHits[1], [2..] before the counters are cleared
+    double q2FracOwn = 0.0;   // (no pool)
+    size_t q2Bytes = 0;
     void *frameArena = nullptr, *chunkArena = nullptr, *resultArena = nullptr;
     size_t resultBytes = 0;   // per-lane traversal results (what k_combine reads)
     uint32_t *counts = nullptr, *heads = nullptr;
@@ -1762,6 +1824,7 @@ void rt_wave_destroy(RtWave *w) {
     if (w->hopEv) (void)hipEventDestroy(w->hopEv);
     if (w->frameArena) (void)hipFree(w->frameArena);
     if (w->chunkArena && !w->pool) (void)hipFree(w->chunkArena);
+    if (w->q2Arena && !w->pool) (void)hipFree(w->q2Arena);
     if (w->resultArena) (void)hipFree(w->resultArena);
     if (w->counts) (void)hipFree(w->counts);
     if (w->heads) (void)hipFree(w->heads);
@@ -1771,7 +1834,7 @@ void rt_wave_destroy(RtWave *w) {
     delete w;
 }
 const char *rt_wave_error(const RtWave *w) { return w->err.c_str(); }
-size_t rt_wave_frame_bytes(const RtWave *w) { return w ? w->slotsCap * (4 + 4 + 4 + sizeof(HitRec) + 16 + 4 + 8 + 8) + (w->pool ? 0 : w->chunkBytes) + w->resultBytes : 0; }
+size_t rt_wave_frame_bytes(const RtWave *w) { return w ? w->slotsCap * (4 + 4 + 4 + sizeof(HitRec) + 16 + 4 + 8 + 8) + (w->pool ? 0 : w->chunkBytes + w->q2Bytes) + w->resultBytes : 0; }
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -1803,13 +1866,15 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
     const size_t perHit = (size_t)(S1 + SPP + S2) * 36 + (size_t)S1 + (size_t)SPP * 12 + (size_t)S2;
     const size_t CHbudget = align_up(std::min(nSlots, std::max<size_t>(w->budgetBytes / perHit, 4096)), 256);
     // ray records + liveness words (read by the traversal launches only: a SHARED arena can be handed on as soon as the last of them is done) ...
+    // (shadow queue 2 -- six slots per bounce HIT -- is an allocation of its own since round 5: q2_bytes(entries per slot))
     auto rays_bytes = [&](size_t ch) {
-        return align_up(ch * (size_t)S1 * 32, 256) + align_up(ch * (size_t)SPP * 32, 256) + align_up(ch * (size_t)S2 * 32, 256) +
-               align_up(ch * (size_t)S1 * 4, 256) + align_up(ch * (size_t)SPP * 4, 256) + align_up(ch * (size_t)S2 * 4, 256) + 4096;
+        return align_up(ch * (size_t)S1 * 32, 256) + align_up(ch * (size_t)SPP * 32, 256) +
+               align_up(ch * (size_t)S1 * 4, 256) + align_up(ch * (size_t)SPP * 4, 256) + 4096;
     };
+    auto q2_bytes = [&](size_t n) { return align_up(n * 6 * 16, 256) * 2 + align_up(n * 6 * 4, 256) + 4096; };
     // ... and the results k_combine reads (1 byte per any-hit ray, 8 per bounce ray, 4 per (hit, sample)): the lane's own
     auto result_bytes = [&](size_t ch) {
-        return align_up(ch * (size_t)S1, 256) + align_up(ch * (size_t)SPP * 8, 256) + align_up(ch * (size_t)S2, 256) + align_up(ch * (size_t)SPP * 4, 256) * 2 + 4096;
+        return align_up(ch * (size_t)S1, 256) + align_up(ch * (size_t)SPP * 8, 256) + align_up(ch * (size_t)S2, 256) * 2 + align_up(ch * (size_t)SPP * 4, 256) * 2 + 4096;
     };
     // arrays that hold `ch` hits (grown, never shrunk; `room`: allocate for that many when growing, so that a batch with a few more hits fits too)
     auto ensure = [&](size_t ch, size_t room) -> int {
@@ -1841,12 +1906,36 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
         }
         return RT_OK;
     };
+    // shadow queue 2 for `n` (hit, sample) pairs per slot: the arena's second allocation, grown like the first
+    // (shrink: a first batch, with nothing known, takes the worst case; once the bounce hits of earlier batches are known an allocation more than three times
+    // what is asked for is given back -- once per arena, behind its current user)
+    auto ensure_q2 = [&](size_t n, size_t room, bool shrink = false) -> int {
+        if (w->pool) {
+            RtArenaPool &P = *w->pool;
+            const int a = w->arena;
+            if (P.bytes2[a] < q2_bytes(n) || (shrink && P.bytes2[a] > 3 * q2_bytes(room))) {
+                if (P.lastUser[a]) W_TRY(hipEventSynchronize(P.freeEv[a]));
+                if (P.mem2[a]) (void)hipFree(P.mem2[a]);
+                P.mem2[a] = nullptr; P.bytes2[a] = 0;
+                W_TRY(hipMalloc(&P.mem2[a], q2_bytes(room)));
+                P.bytes2[a] = q2_bytes(room);
+            }
+            w->q2Arena = P.mem2[a];
+        } else if (w->q2Bytes < q2_bytes(n)) {
+            if (w->q2Arena) { W_TRY(hipStreamSynchronize(st)); (void)hipFree(w->q2Arena); }
+            w->q2Arena = nullptr;
+            w->q2Bytes = 0;
+            W_TRY(hipMalloc(&w->q2Arena, q2_bytes(room)));
+            w->q2Bytes = q2_bytes(room);
+        }
+        return RT_OK;
+    };
     // Round 4: a launch set whose queues would be large if every pixel slot were a hit (a batch of eight 1080p frames: 30 GB) is sized from its HIT count --
     // read back once, behind k_post_primary, on this lane's stream only (the other lanes keep the GPU busy: 1.726 vs 1.719 ms per frame with and without
     // that read-back, profiles/r04_experiments.txt) -- instead of from the budget.  Small launch sets (and RT_CHUNKS_FROM_SLOTS) are sized from their pixel
     // slots as before and never wait for the host.
     constexpr size_t kComfortBytes = (size_t)4 << 30;
-    const bool deferred = !w->chunksFromSlots && rays_bytes(CHbudget) > kComfortBytes;
+    const bool deferred = !w->chunksFromSlots && rays_bytes(CHbudget) + q2_bytes(CHbudget * (size_t)SPP) > kComfortBytes;
     size_t CH = CHbudget;
     WaveBuf wb;
     auto carve = [&](size_t ch) {
@@ -1854,15 +1943,21 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
         auto take = [&](size_t bytes) { char *r = q; q += align_up(bytes, 256); return r; };
         wb.shO = (float4 *)take(ch * (size_t)S1 * 16); wb.shD = (float4 *)take(ch * (size_t)S1 * 16);
         wb.giO = (float4 *)take(ch * (size_t)SPP * 16); wb.giD = (float4 *)take(ch * (size_t)SPP * 16);
-        wb.sh2O = (float4 *)take(ch * (size_t)S2 * 16); wb.sh2D = (float4 *)take(ch * (size_t)S2 * 16);
-        wb.shT = (float *)take(ch * (size_t)S1 * 4); wb.giL = (float *)take(ch * (size_t)SPP * 4); wb.sh2T = (float *)take(ch * (size_t)S2 * 4);
+        wb.shT = (float *)take(ch * (size_t)S1 * 4); wb.giL = (float *)take(ch * (size_t)SPP * 4);
         q = (char *)w->resultArena;
         wb.occ1 = (uint8_t *)take(ch * (size_t)S1);
         wb.giT = (float *)take(ch * (size_t)SPP * 4); wb.giTri = (int *)take(ch * (size_t)SPP * 4);
         wb.occ2 = (uint8_t *)take(ch * (size_t)S2);
+        wb.occOvf = (uint8_t *)take(ch * (size_t)S2);
         wb.giPos = (int *)take(ch * (size_t)SPP * 4);
         wb.giPerm = w->binGi ? (int *)take(ch * (size_t)SPP * 4) : nullptr;
         wb.CH = (uint32_t)ch;
+    };
+    auto carve_q2 = [&](size_t n) {       // n entries per slot (a multiple of 64)
+        char *q = (char *)w->q2Arena;
+        auto take = [&](size_t bytes) { char *r = q; q += align_up(bytes, 256); return r; };
+        wb.sh2O = (float4 *)take(n * 6 * 16); wb.sh2D = (float4 *)take(n * 6 * 16); wb.sh2T = (float *)take(n * 6 * 4);
+        wb.q2Stride = (uint32_t)n;
     };
     if (CHbudget * (size_t)std::max(S1, S2) >= ((size_t)1 << 31)) { w->err = "ray queue chunk exceeds 2^31 entries; lower RT_QUEUE_BUDGET_MB"; return RT_ERR_UNSUPPORTED; }
     {
@@ -1877,12 +1972,18 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
         wb.pendMy = (float *)p;
     }
     wb.shO = wb.shD = wb.giO = wb.giD = wb.sh2O = wb.sh2D = nullptr; wb.shT = wb.giL = wb.sh2T = nullptr;   // (deferred: carved behind k_post_primary)
-    wb.occ1 = wb.occ2 = nullptr; wb.giT = nullptr; wb.giTri = wb.giPos = wb.giPerm = nullptr;
+    wb.occ1 = wb.occ2 = wb.occOvf = nullptr; wb.giT = nullptr; wb.giTri = wb.giPos = wb.giPerm = nullptr;
+    wb.q2Stride = 0;
     if (!deferred) {
         if (w->pool) w->arena = (nSlots + CH - 1) / CH > 1 ? w->lane : w->lane % w->pool->n;
         int rc = ensure(CH, CH);
         if (rc != RT_OK) return rc;
         carve(CH);
+        size_t n2 = CH * (size_t)SPP;                             // small launch sets: every bounce ray may hit
+        if (const char *e = getenv("RT_Q2_CAP")) n2 = align_up(std::min<size_t>(n2, std::max<size_t>((size_t)atoll(e), 64)), 64);   // tests: force the overflow path
+        rc = ensure_q2(n2, n2);
+        if (rc != RT_OK) return rc;
+        carve_q2(n2);
     }
     wb.CH = (uint32_t)CH; wb.A = A; wb.SPP = SPP;
     int nChunks = (int)((nSlots + CH - 1) / CH);   // upper bound (every pixel slot a hit); cut down to the hit count below
@@ -1895,6 +1996,7 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
         if (w->heads) (void)hipFree(w->heads);
         w->counts = w->heads = nullptr;
         w->launchCap = w->chunkCap = 0;
+        w->prevChunks = 0;
         const int lc = std::max(kMinLaunches, 1 + nChunks * 4), cc = std::max(4096, nChunks);
         W_TRY(hipMalloc(&w->counts, (size_t)(64 + cc) * sizeof(uint32_t)));
         W_TRY(hipMalloc(&w->heads, (size_t)lc * kHeadWords * sizeof(uint32_t)));
@@ -1902,6 +2004,14 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
     }
     wb.counts = w->counts; wb.heads = w->heads;
 
+    // the bounce-hit counts of this lane's PREVIOUS launch set, before they are cleared: read on the host behind this set's own hit-count read-back (no extra
+    // synchronisation) -- what the capacity of shadow queue 2 is predicted from
+    if (!w->hostHits) W_TRY(hipHostMalloc((void **)&w->hostHits, 64 * sizeof(uint32_t)));
+    const int giCopied = std::min(w->prevChunks, 60);
+    if (giCopied > 0) {
+        W_TRY(hipMemcpyAsync(w->hostHits + 1, w->counts + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        W_TRY(hipMemcpyAsync(w->hostHits + 2, w->counts + 64, (size_t)giCopied * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    }
     W_TRY(hipMemsetAsync(w->counts, 0, (size_t)(64 + nChunks) * sizeof(uint32_t), st));
     W_TRY(hipMemsetAsync(w->heads, 0, (size_t)(1 + nChunks * 4) * kHeadWords * sizeof(uint32_t), st));
     // Persistent grids smaller than what fits, for the two queue launches of a cache-resident scene: they run near the vector L1's access
@@ -1957,10 +2067,15 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
     // milliseconds of work, so the hit count is read back once (this lane's stream only; the other lanes keep the GPU busy) and
     // the hits are dealt over equal chunks.  A single-chunk frame -- every frame-by-frame BASELINE configuration -- never syncs.
     if ((deferred || nChunks > 1) && !w->chunksFromSlots) {
-        if (!w->hostHits) W_TRY(hipHostMalloc((void **)&w->hostHits, sizeof(uint32_t)));
         W_TRY(hipMemcpyAsync(w->hostHits, &w->counts[1], sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         W_TRY(hipStreamSynchronize(st));
         const size_t hits = *w->hostHits;
+        if (giCopied > 0 && w->hostHits[1] > 0) {     // the previous launch set of this lane: what share of its (hit, sample) pairs had a bounce hit
+            unsigned long long bounced = 0;
+            for (int i = 0; i < giCopied; ++i) bounced += w->hostHits[2 + i];
+            double &frac = w->pool ? w->pool->q2Frac : w->q2FracOwn;
+            frac = std::max(frac, std::max(1e-9, (double)bounced / ((double)w->hostHits[1] * (double)std::max(w->prevSPP, 1))));
+        }
         nChunks = (int)((hits + CHbudget - 1) / CHbudget);
         if (nChunks > 0) CH = align_up((hits + (size_t)nChunks - 1) / (size_t)nChunks, 256);
         // a set of several chunks keeps its arena for the whole chunk loop -- shared by two lanes that would serialise the lanes (4 spp -> 16 spp, 4K and
@@ -1975,6 +2090,21 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
             if (rc != RT_OK) return rc;
         }
         if (nChunks > 0) carve(CH);
+        if (nChunks > 0 && u.enableGI == 1) {
+            // Shadow queue 2 (round 5): six ray records per bounce HIT.  Sized for the worst case -- every bounce ray hits -- it was 48 % of the ray
+            // arenas; on the bench view 1 % of that is used.  A large launch set sizes it from what earlier batches needed: twice the largest share of bounce hits any launch set has had
+            // (the worst case while nothing is known yet -- the first batch of each lane -- given back afterwards: the in-place path is an order of magnitude slower per
+            // ray than the queue, 1 M-triangle scene: 20 ms per frame when half the pairs overflow), and pairs beyond the capacity -- a view whose bounce hits more than
+            // doubled from one batch to the next -- are traced in place by k_gen_gi_overflow instead of queued.
+            const double seen = w->pool ? w->pool->q2Frac : w->q2FracOwn;
+            const size_t worst = CH * (size_t)SPP;
+            size_t n2 = seen > 0.0 ? std::max<size_t>((size_t)(2.0 * seen * (double)worst) + 65536, worst / 32) : worst;
+            n2 = align_up(std::min(n2, worst), 64);
+            if (const char *e = getenv("RT_Q2_CAP")) n2 = align_up(std::min<size_t>(worst, std::max<size_t>((size_t)atoll(e), 64)), 64);   // tests: force the overflow path
+            int rc = ensure_q2(n2, n2, seen > 0.0);
+            if (rc != RT_OK) return rc;
+            carve_q2(n2);
+        }
     }
     // shared arena: everything from here to the last combine reads or writes it
     if (w->pool && nChunks > 0 && w->pool->lastUser[w->arena] && w->pool->lastUser[w->arena] != st) W_TRY(hipStreamWaitEvent(st, w->pool->freeEv[w->arena], 0));
@@ -2014,13 +2144,15 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
             W_TRY(hop(st, ss));
             rt_stage_begin(ctx, ST_GEN_GI, ss);
             hipLaunchKernelGGL(k_gen_gi, dim3(gridHS), dim3(256), 0, ss, dFrame, wb, c0, &wb.counts[64 + c]);
+            if (wb.q2Stride < wb.CH * (uint32_t)SPP)   // a predicted capacity: the pairs beyond it (normally none) trace their rays in place
+                hipLaunchKernelGGL(k_gen_gi_overflow, dim3(gridHS), dim3(256), (size_t)256 * std::max(treeDepth, 4) * 8, ss, dFrame, wb, c0, &wb.counts[64 + c], std::max(treeDepth, 4));
             rt_stage_end(ctx, ST_GEN_GI, 1, ss);
             W_TRY(hop(ss, st));
 
             DualQueueSrc qq;
             qq.a = q1;
-            qq.b.o = wb.sh2O; qq.b.d = wb.sh2D; qq.b.tm = wb.sh2T; qq.b.liveCount = &wb.counts[64 + c]; qq.b.c0 = 0; qq.b.cap = wb.CH * (uint32_t)SPP;
-            qq.b.stride = wb.CH * (uint32_t)SPP; qq.b.slots = 6u; qq.b.denseSlots = 0u;
+            qq.b.o = wb.sh2O; qq.b.d = wb.sh2D; qq.b.tm = wb.sh2T; qq.b.liveCount = &wb.counts[64 + c]; qq.b.c0 = 0; qq.b.cap = wb.q2Stride;
+            qq.b.stride = wb.q2Stride; qq.b.slots = 6u; qq.b.denseSlots = 0u;
             qq.b.outT = nullptr; qq.b.outTri = nullptr; qq.b.outOcc = wb.occ2;
             rt_stage_begin(ctx, ST_TRACE_SHADOW, st);
             launch_trace<DualQueueSrc, true>(st, w->cus, gridPct, treeDepth, dFrame, host.sc, qq, &wb.heads[(size_t)(1 + c * 4 + 0) * kHeadWords], w->acc + 3, w->acc + 9, tune, S ? S + 16 : nullptr);
@@ -2038,6 +2170,8 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
         rt_stage_end(ctx, ST_COMBINE, 1, ss);
         W_TRY(hop(ss, st));
     }
+    w->prevChunks = (u.enableGI == 1) ? nChunks : 0;
+    w->prevSPP = SPP;
     hipLaunchKernelGGL(k_accum_tally, dim3(1), dim3(64), 0, st, w->counts, w->acc, batch);
     // temporal resolve: the one stage that needs the previous frame's COLOR0 (and must not overtake its target stores)
     if (evPrevDone) W_TRY(hipStreamWaitEvent(st, evPrevDone, 0));

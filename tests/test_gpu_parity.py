@@ -459,6 +459,45 @@ def test_bvh_scene_frames_wavefront(ren_wave, orc, cam_kind, spp):
         prev = want[0]
 
 
+@pytest.mark.parametrize("cap", [64, 1024])
+def test_shadow_queue_2_overflow_is_traced_in_place(orc, monkeypatch, cap):
+    """Round 5: a large launch set sizes shadow queue 2 (six ray records per bounce HIT) from the bounce hits of earlier batches instead of for the worst case, and
+    the (hit, sample) pairs beyond that capacity trace their six rays in place (k_gen_gi_overflow, the megakernel's any-hit walk) instead of queueing them.  RT_Q2_CAP
+    forces a capacity of 64 / 1024 pairs on a frame whose bounce rays hit the mesh thousands of times: the any-hit launch then traces only the queued part, the frames
+    must still be the oracle's bit for bit -- frame by frame and as a batch of three."""
+    W, H = 200, 120
+    # the stand-in mesh twice, the second copy shifted so that the two face each other: bounce rays leaving one hit the other
+    v, f = rt.meshgen.bunny_standin(4)
+    a = rt.gather_triangles(v, f)
+    b = a.copy()
+    b[:, 0] += np.float32(0.7); b[:, 2] += np.float32(0.5)           # rows are (v0, e1, e2): only the base vertex moves
+    nodes, tris = rt.build_bvh(np.concatenate([a, b]).astype(np.float32))
+    faces = scenes.tiny_env(16)
+    p = rt.default_render_params()
+    p.sppPerFrame = 3
+    cam = scenes.camera("closeup", aspect=W / H)
+    us = [rt.frame_uniforms(p, cam, W, H, f_, True, nodes.shape[0], tris.shape[0]) for f_ in range(3)]
+    with rt.Renderer(pipeline=rt.RT_PIPELINE_WAVEFRONT) as r:
+        r.upload_bvh(nodes, tris); r.upload_env(faces); r.resize(W, H)
+        for u in us:
+            r.render_frame(u)
+        full = r.traced_rays(True).shadow                 # (the one any-hit launch tallies both shadow queues)
+    monkeypatch.setenv("RT_Q2_CAP", str(cap))
+    with rt.Renderer(pipeline=rt.RT_PIPELINE_WAVEFRONT) as r, rt.Renderer(pipeline=rt.RT_PIPELINE_WAVEFRONT) as rb:
+        r.upload_bvh(nodes, tris); r.upload_env(faces); r.resize(W, H)
+        rb.upload_bvh(nodes, tris); rb.upload_env(faces); rb.resize(W, H)
+        prev = None
+        for f, u in enumerate(us):
+            r.render_frame(u)
+            want, _ = orc.render(u, nodes, tris, faces, prev)
+            _assert_targets_equal(r.read_all(), want, orc, f"RT_Q2_CAP={cap} frame={f}")
+            prev = want[0]
+        capped = r.traced_rays(True).shadow
+        rb.render_frames(us)
+        _assert_targets_equal(rb.read_all(), want, orc, f"RT_Q2_CAP={cap} batch of three")
+    assert full - capped > 2000, (full, capped)      # the queue really was too small: thousands of bounce-hit shadow rays were traced in place, not by the launch
+
+
 @pytest.mark.parametrize("spp,W,H", [(16, 96, 64), (64, 48, 40)])
 def test_bvh_wavefront_high_spp(ren_wave, orc, spp, W, H):
     """BASELINE configs 3-5 run at 16 and 64 spp: the ray queues hold 6*spp + aoSamples slots per hit, frames stay bit-exact."""
