@@ -284,9 +284,12 @@ def main():
                 gather_path["path"] = ("torch.distributed (gloo, blocks staged through host memory): REHEARSAL, every rank on GPU 0" if args.rehearse_one_gpu
                                        else "torch.distributed (RCCL) on the library's device pointers")
         # setup, not a step: every frame lane (3-4 streams with their own ray-queue arenas) allocates on its first frame; do that
-        # before the W warm-up steps so that a small W cannot push a multi-GB hipMalloc into the timed region
-        setup_u = [uniforms(cam, f) for f in range(5 * B)]
-        for b in range(5):
+        # before the W warm-up steps so that a small W cannot push a multi-GB hipMalloc into the timed region.  Round 5: twelve batches instead of five --
+        # the library gives the worst-case part of a ray arena back once it knows the scene's share of bounce hits (a lane's SECOND large launch set), and an
+        # arena that was reallocated is used at least twice before anything is timed
+        N_SETUP = int(os.environ.get("RT_BENCH_SETUP_BATCHES", "12"))
+        setup_u = [uniforms(cam, f) for f in range(N_SETUP * B)]
+        for b in range(N_SETUP):
             ren.render_frames(setup_u[b * B:(b + 1) * B])
             if gatherer:
                 gatherer.after(B, last=True)

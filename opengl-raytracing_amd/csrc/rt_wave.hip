@@ -1603,22 +1603,25 @@ struct GenGiOverflowTracer {
     RT_DEV bool ao(int, V3, V3, float) { return false; }
 };
 __global__ __launch_bounds__(256) void k_gen_gi_overflow(const DevFrame *__restrict__ fr, WaveBuf wb, uint32_t c0, const uint32_t *giCount, int stackEntries) {
-    if (*giCount <= wb.q2Stride) return;
+    if (*giCount <= wb.q2Stride) return;      // the normal case: a small fixed grid that leaves at once (a grid of one thread per pair -- 29 000 workgroups for a batch of eight
+                                              // 1080p frames -- cost 2 % of a frame just to be dispatched and return)
     const uint32_t live = chunk_live(wb, c0);
-    const uint32_t tid = blockIdx.x * 256 + threadIdx.x;
-    if (live == 0 || tid >= live * (uint32_t)wb.SPP) return;
-    const int s = (int)(tid / live);
-    const uint32_t j = tid % live;
-    const int gp = wb.giPos[(uint32_t)s * wb.CH + j];
-    if (gp < 0 || (uint32_t)gp < wb.q2Stride) return;
-    GenGiOverflowTracer tr;
-    tr.wb = wb; tr.sc = &fr->sc; tr.eps = fr->u.eps; tr.j = j; tr.s = s; tr.pos = (uint32_t)gp;
-    tr.stk = reinterpret_cast<StackEntry *>(rt_dyn_lds) + (threadIdx.x >> 6) * stackEntries * 64 + (threadIdx.x & 63);
-    HitCtx c = load_hit(fr, wb.hits[c0 + j]);
-    const int SPP = max(fr->u.spp, 1);
-    const int seed = (int)((uint32_t)c.F.frameIndex * (uint32_t)SPP + (uint32_t)s);
-    Work w;
-    (void)oneBounceGIBVH<GenGiOverflowTracer, false>(tr, c.F, c.hp, c.hn, c.F.frameIndex, seed, w);
+    if (live == 0) return;
+    const uint32_t n = live * (uint32_t)wb.SPP;
+    for (uint32_t tid = blockIdx.x * 256 + threadIdx.x; tid < n; tid += gridDim.x * 256) {
+        const int s = (int)(tid / live);
+        const uint32_t j = tid % live;
+        const int gp = wb.giPos[(uint32_t)s * wb.CH + j];
+        if (gp < 0 || (uint32_t)gp < wb.q2Stride) continue;
+        GenGiOverflowTracer tr;
+        tr.wb = wb; tr.sc = &fr->sc; tr.eps = fr->u.eps; tr.j = j; tr.s = s; tr.pos = (uint32_t)gp;
+        tr.stk = reinterpret_cast<StackEntry *>(rt_dyn_lds) + (threadIdx.x >> 6) * stackEntries * 64 + (threadIdx.x & 63);
+        HitCtx c = load_hit(fr, wb.hits[c0 + j]);
+        const int SPP = max(fr->u.spp, 1);
+        const int seed = (int)((uint32_t)c.F.frameIndex * (uint32_t)SPP + (uint32_t)s);
+        Work w;
+        (void)oneBounceGIBVH<GenGiOverflowTracer, false>(tr, c.F, c.hp, c.hn, c.F.frameIndex, seed, w);
+    }
 }
 
 // ---- stage: combine (thread = hit) ---------------------------------------------------------------
@@ -1727,10 +1730,9 @@ struct RtArenaPool {
     int n = 0;
     void *mem[RT_MAX_LANES] = {};
     size_t bytes[RT_MAX_LANES] = {};
-    void *mem2[RT_MAX_LANES] = {};             // shadow queue 2 of the arena: its own allocation, sized -- for large launch sets -- from the bounce hits of earlier batches
     double q2Frac = 0.0;                       // largest share of (hit, sample) pairs whose bounce ray hit, over the launch sets of all lanes so far (read back with the NEXT
                                                // launch set's hit count: no extra synchronisation); 0: nothing known yet
-    size_t bytes2[RT_MAX_LANES] = {};
+    size_t maxCh[RT_MAX_LANES] = {};           // most hits an arena has been sized for
     hipEvent_t freeEv[RT_MAX_LANES] = {};      // recorded behind the last kernel of the batch that used the arena last
     hipStream_t lastUser[RT_MAX_LANES] = {};   // (a later batch on the same stream is ordered behind it anyway)
 };
@@ -1742,11 +1744,11 @@ RtArenaPool *rt_arena_pool_create(int arenas) {
 }
 void rt_arena_pool_destroy(RtArenaPool *p) {
     if (!p) return;
-    for (int i = 0; i < RT_MAX_LANES; ++i) { if (p->mem[i]) (void)hipFree(p->mem[i]); if (p->mem2[i]) (void)hipFree(p->mem2[i]); if (p->freeEv[i]) (void)hipEventDestroy(p->freeEv[i]); }
+    for (int i = 0; i < RT_MAX_LANES; ++i) { if (p->mem[i]) (void)hipFree(p->mem[i]); if (p->freeEv[i]) (void)hipEventDestroy(p->freeEv[i]); }
     delete p;
 }
 int rt_arena_pool_count(const RtArenaPool *p) { int c = 0; for (int i = 0; p && i < RT_MAX_LANES; ++i) c += p->mem[i] ? 1 : 0; return c; }
-size_t rt_arena_pool_bytes(const RtArenaPool *p) { size_t b = 0; for (int i = 0; p && i < RT_MAX_LANES; ++i) b += p->bytes[i] + p->bytes2[i]; return b; }
+size_t rt_arena_pool_bytes(const RtArenaPool *p) { size_t b = 0; for (int i = 0; p && i < RT_MAX_LANES; ++i) b += p->bytes[i]; return b; }
 
 struct RtWave {
     std::string err;
@@ -1761,10 +1763,8 @@ struct RtWave {
     // allocations
     size_t slotsCap = 0;      // per-frame arrays sized for this many pixel slots
     size_t chunkBytes = 0;    // bytes of the per-chunk arena
-    void *q2Arena = nullptr;  // shadow queue 2 (pool: the arena's mem2)
     int prevChunks = 0, prevSPP = 1;   // chunks / spp of this lane's previous launch set: its hit count and bounce-hit counts are copied to hostHits[1], [2..] before the counters are cleared
     double q2FracOwn = 0.0;   // (no pool)
-    size_t q2Bytes = 0;
     void *frameArena = nullptr, *chunkArena = nullptr, *resultArena = nullptr;
     size_t resultBytes = 0;   // per-lane traversal results (what k_combine reads)
     uint32_t *counts = nullptr, *heads = nullptr;
@@ -1824,7 +1824,6 @@ void rt_wave_destroy(RtWave *w) {
     if (w->hopEv) (void)hipEventDestroy(w->hopEv);
     if (w->frameArena) (void)hipFree(w->frameArena);
     if (w->chunkArena && !w->pool) (void)hipFree(w->chunkArena);
-    if (w->q2Arena && !w->pool) (void)hipFree(w->q2Arena);
     if (w->resultArena) (void)hipFree(w->resultArena);
     if (w->counts) (void)hipFree(w->counts);
     if (w->heads) (void)hipFree(w->heads);
@@ -1834,7 +1833,7 @@ void rt_wave_destroy(RtWave *w) {
     delete w;
 }
 const char *rt_wave_error(const RtWave *w) { return w->err.c_str(); }
-size_t rt_wave_frame_bytes(const RtWave *w) { return w ? w->slotsCap * (4 + 4 + 4 + sizeof(HitRec) + 16 + 4 + 8 + 8) + (w->pool ? 0 : w->chunkBytes + w->q2Bytes) + w->resultBytes : 0; }
+size_t rt_wave_frame_bytes(const RtWave *w) { return w ? w->slotsCap * (4 + 4 + 4 + sizeof(HitRec) + 16 + 4 + 8 + 8) + (w->pool ? 0 : w->chunkBytes) + w->resultBytes : 0; }
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -1877,7 +1876,23 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
         return align_up(ch * (size_t)S1, 256) + align_up(ch * (size_t)SPP * 8, 256) + align_up(ch * (size_t)S2, 256) * 2 + align_up(ch * (size_t)SPP * 4, 256) * 2 + 4096;
     };
     // arrays that hold `ch` hits (grown, never shrunk; `room`: allocate for that many when growing, so that a batch with a few more hits fits too)
+    // Shadow queue 2 (round 5): six ray records per bounce HIT, behind queue 1 in the same allocation.  Sized for the worst case -- every bounce ray
+    // hits -- it was 48 % of the ray arenas; on the bench view 1 % of that is used.  A LARGE launch set (sized from its hit count anyway) sizes it from what earlier
+    // launch sets needed: twice the largest share of (hit, sample) pairs that bounced so far + slack, the worst case while nothing is known; pairs beyond the capacity -- a
+    // view whose bounce hits more than doubled -- are traced in place by k_gen_gi_overflow instead of queued (an order of magnitude slower per ray: 1 M-triangle scene, 20 ms
+    // per frame with half the pairs overflowing -- hence never a guess below the worst case).  Small launch sets take the worst case, no question asked of the device.
+    const double &q2Share = w->pool ? w->pool->q2Frac : w->q2FracOwn;   // (live: updated behind this set's hit-count read-back, before a large set sizes its arena)
+    bool predictQ2 = false;          // set for deferred sets below
+    auto n2_of = [&](size_t ch) -> size_t {
+        const size_t worst = ch * (size_t)SPP;
+        static const bool predictOn = !(getenv("RT_Q2_PREDICT") && atoi(getenv("RT_Q2_PREDICT")) == 0);   // RT_Q2_PREDICT=0: always the worst case, as in rounds 1-4 (A/B)
+        size_t n2 = (predictOn && predictQ2 && q2Share > 0.0) ? std::max<size_t>((size_t)(2.0 * q2Share * (double)worst) + 65536, worst / 32) : worst;
+        if (const char *e = getenv("RT_Q2_CAP")) n2 = std::max<size_t>((size_t)atoll(e), 64);   // tests: force the overflow path
+        return align_up(std::min(n2, worst), 64);
+    };
+    auto arena_bytes = [&](size_t ch) { return rays_bytes(ch) + q2_bytes(n2_of(ch)); };
     auto ensure = [&](size_t ch, size_t room) -> int {
+        room = std::max(room, ch);
         if (w->resultBytes < result_bytes(ch)) {
             if (w->resultArena) { W_TRY(hipStreamSynchronize(st)); (void)hipFree(w->resultArena); }
             w->resultArena = nullptr;
@@ -1889,44 +1904,27 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
             // a shared arena: grown once its current user is done with it
             RtArenaPool &P = *w->pool;
             const int a = w->arena;
-            if (P.bytes[a] < rays_bytes(ch)) {
+            // (grown when too small; given back ONCE it is more than 1.6 x what a launch set asks for now that the share of bounce hits is known: the worst-case
+            // allocation of the first launch sets.  Either way behind the arena's current user.)
+            // The new size is for the LARGEST launch set the arena has held, not for this one: bench.py's five-frame warm-up batch once shrank an arena that the
+            // seven-frame batches of the timed region then had to grow again (a device-wide synchronisation and a multi-gigabyte hipMalloc inside a 34 ms region:
+            // 1.65 -> 1.81 ms per step).
+            room = std::max(room, P.maxCh[a]);
+            if (P.bytes[a] < arena_bytes(ch) || (predictQ2 && q2Share > 0.0 && getenv("RT_Q2_PREDICT") == nullptr && P.bytes[a] > arena_bytes(room) + arena_bytes(room) / 2 + arena_bytes(room) / 10)) {
                 if (P.lastUser[a]) W_TRY(hipEventSynchronize(P.freeEv[a]));
                 if (P.mem[a]) (void)hipFree(P.mem[a]);
                 P.mem[a] = nullptr; P.bytes[a] = 0;
-                W_TRY(hipMalloc(&P.mem[a], rays_bytes(room)));
-                P.bytes[a] = rays_bytes(room);
+                W_TRY(hipMalloc(&P.mem[a], arena_bytes(room)));
+                P.bytes[a] = arena_bytes(room);
             }
+            P.maxCh[a] = room;
             w->chunkArena = P.mem[a];
-        } else if (w->chunkBytes < rays_bytes(ch)) {
+        } else if (w->chunkBytes < arena_bytes(ch)) {
             if (w->chunkArena) { W_TRY(hipStreamSynchronize(st)); (void)hipFree(w->chunkArena); }
             w->chunkArena = nullptr;
             w->chunkBytes = 0;
-            W_TRY(hipMalloc(&w->chunkArena, rays_bytes(room)));
-            w->chunkBytes = rays_bytes(room);
-        }
-        return RT_OK;
-    };
-    // shadow queue 2 for `n` (hit, sample) pairs per slot: the arena's second allocation, grown like the first
-    // (shrink: a first batch, with nothing known, takes the worst case; once the bounce hits of earlier batches are known an allocation more than three times
-    // what is asked for is given back -- once per arena, behind its current user)
-    auto ensure_q2 = [&](size_t n, size_t room, bool shrink = false) -> int {
-        if (w->pool) {
-            RtArenaPool &P = *w->pool;
-            const int a = w->arena;
-            if (P.bytes2[a] < q2_bytes(n) || (shrink && P.bytes2[a] > 3 * q2_bytes(room))) {
-                if (P.lastUser[a]) W_TRY(hipEventSynchronize(P.freeEv[a]));
-                if (P.mem2[a]) (void)hipFree(P.mem2[a]);
-                P.mem2[a] = nullptr; P.bytes2[a] = 0;
-                W_TRY(hipMalloc(&P.mem2[a], q2_bytes(room)));
-                P.bytes2[a] = q2_bytes(room);
-            }
-            w->q2Arena = P.mem2[a];
-        } else if (w->q2Bytes < q2_bytes(n)) {
-            if (w->q2Arena) { W_TRY(hipStreamSynchronize(st)); (void)hipFree(w->q2Arena); }
-            w->q2Arena = nullptr;
-            w->q2Bytes = 0;
-            W_TRY(hipMalloc(&w->q2Arena, q2_bytes(room)));
-            w->q2Bytes = q2_bytes(room);
+            W_TRY(hipMalloc(&w->chunkArena, arena_bytes(room)));
+            w->chunkBytes = arena_bytes(room);
         }
         return RT_OK;
     };
@@ -1944,6 +1942,9 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
         wb.shO = (float4 *)take(ch * (size_t)S1 * 16); wb.shD = (float4 *)take(ch * (size_t)S1 * 16);
         wb.giO = (float4 *)take(ch * (size_t)SPP * 16); wb.giD = (float4 *)take(ch * (size_t)SPP * 16);
         wb.shT = (float *)take(ch * (size_t)S1 * 4); wb.giL = (float *)take(ch * (size_t)SPP * 4);
+        const size_t n2 = n2_of(ch);
+        wb.sh2O = (float4 *)take(n2 * 6 * 16); wb.sh2D = (float4 *)take(n2 * 6 * 16); wb.sh2T = (float *)take(n2 * 6 * 4);
+        wb.q2Stride = (uint32_t)n2;
         q = (char *)w->resultArena;
         wb.occ1 = (uint8_t *)take(ch * (size_t)S1);
         wb.giT = (float *)take(ch * (size_t)SPP * 4); wb.giTri = (int *)take(ch * (size_t)SPP * 4);
@@ -1952,12 +1953,6 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
         wb.giPos = (int *)take(ch * (size_t)SPP * 4);
         wb.giPerm = w->binGi ? (int *)take(ch * (size_t)SPP * 4) : nullptr;
         wb.CH = (uint32_t)ch;
-    };
-    auto carve_q2 = [&](size_t n) {       // n entries per slot (a multiple of 64)
-        char *q = (char *)w->q2Arena;
-        auto take = [&](size_t bytes) { char *r = q; q += align_up(bytes, 256); return r; };
-        wb.sh2O = (float4 *)take(n * 6 * 16); wb.sh2D = (float4 *)take(n * 6 * 16); wb.sh2T = (float *)take(n * 6 * 4);
-        wb.q2Stride = (uint32_t)n;
     };
     if (CHbudget * (size_t)std::max(S1, S2) >= ((size_t)1 << 31)) { w->err = "ray queue chunk exceeds 2^31 entries; lower RT_QUEUE_BUDGET_MB"; return RT_ERR_UNSUPPORTED; }
     {
@@ -1979,11 +1974,6 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
         int rc = ensure(CH, CH);
         if (rc != RT_OK) return rc;
         carve(CH);
-        size_t n2 = CH * (size_t)SPP;                             // small launch sets: every bounce ray may hit
-        if (const char *e = getenv("RT_Q2_CAP")) n2 = align_up(std::min<size_t>(n2, std::max<size_t>((size_t)atoll(e), 64)), 64);   // tests: force the overflow path
-        rc = ensure_q2(n2, n2);
-        if (rc != RT_OK) return rc;
-        carve_q2(n2);
     }
     wb.CH = (uint32_t)CH; wb.A = A; wb.SPP = SPP;
     int nChunks = (int)((nSlots + CH - 1) / CH);   // upper bound (every pixel slot a hit); cut down to the hit count below
@@ -2082,6 +2072,7 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
         // the 1 M-triangle scene lost 3 % that way) -- so it takes the lane's OWN arena; one-chunk sets (every frame-by-frame configuration, bench.py's
         // batches) share lane % n
         if (w->pool && deferred) w->arena = nChunks > 1 ? w->lane : w->lane % w->pool->n;   // (not deferred: chosen and allocated before k_primary)
+        predictQ2 = deferred;
         if (deferred && nChunks > 0) {
             // the arenas hold this launch set's hits (+ 6 % when they have to grow); a set of several chunks gets the whole budget at once: its chunk size
             // changes with the number of frames in the batch (20 M hits = 3 x 6.7 M, 17 M = 2 x 8.6 M), and growing a 16 GB arena in the middle of a run
@@ -2090,21 +2081,6 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
             if (rc != RT_OK) return rc;
         }
         if (nChunks > 0) carve(CH);
-        if (nChunks > 0 && u.enableGI == 1) {
-            // Shadow queue 2 (round 5): six ray records per bounce HIT.  Sized for the worst case -- every bounce ray hits -- it was 48 % of the ray
-            // arenas; on the bench view 1 % of that is used.  A large launch set sizes it from what earlier batches needed: twice the largest share of bounce hits any launch set has had
-            // (the worst case while nothing is known yet -- the first batch of each lane -- given back afterwards: the in-place path is an order of magnitude slower per
-            // ray than the queue, 1 M-triangle scene: 20 ms per frame when half the pairs overflow), and pairs beyond the capacity -- a view whose bounce hits more than
-            // doubled from one batch to the next -- are traced in place by k_gen_gi_overflow instead of queued.
-            const double seen = w->pool ? w->pool->q2Frac : w->q2FracOwn;
-            const size_t worst = CH * (size_t)SPP;
-            size_t n2 = seen > 0.0 ? std::max<size_t>((size_t)(2.0 * seen * (double)worst) + 65536, worst / 32) : worst;
-            n2 = align_up(std::min(n2, worst), 64);
-            if (const char *e = getenv("RT_Q2_CAP")) n2 = align_up(std::min<size_t>(worst, std::max<size_t>((size_t)atoll(e), 64)), 64);   // tests: force the overflow path
-            int rc = ensure_q2(n2, n2, seen > 0.0);
-            if (rc != RT_OK) return rc;
-            carve_q2(n2);
-        }
     }
     // shared arena: everything from here to the last combine reads or writes it
     if (w->pool && nChunks > 0 && w->pool->lastUser[w->arena] && w->pool->lastUser[w->arena] != st) W_TRY(hipStreamWaitEvent(st, w->pool->freeEv[w->arena], 0));
@@ -2145,7 +2121,7 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
             rt_stage_begin(ctx, ST_GEN_GI, ss);
             hipLaunchKernelGGL(k_gen_gi, dim3(gridHS), dim3(256), 0, ss, dFrame, wb, c0, &wb.counts[64 + c]);
             if (wb.q2Stride < wb.CH * (uint32_t)SPP)   // a predicted capacity: the pairs beyond it (normally none) trace their rays in place
-                hipLaunchKernelGGL(k_gen_gi_overflow, dim3(gridHS), dim3(256), (size_t)256 * std::max(treeDepth, 4) * 8, ss, dFrame, wb, c0, &wb.counts[64 + c], std::max(treeDepth, 4));
+                hipLaunchKernelGGL(k_gen_gi_overflow, dim3(std::min<unsigned>(gridHS, (unsigned)w->cus * 4u)), dim3(256), (size_t)256 * std::max(treeDepth, 4) * 8, ss, dFrame, wb, c0, &wb.counts[64 + c], std::max(treeDepth, 4));
             rt_stage_end(ctx, ST_GEN_GI, 1, ss);
             W_TRY(hop(ss, st));
 
