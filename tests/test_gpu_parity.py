@@ -477,6 +477,7 @@ def test_shadow_queue_2_overflow_is_traced_in_place(orc, monkeypatch, cap):
     p.sppPerFrame = 3
     cam = scenes.camera("closeup", aspect=W / H)
     us = [rt.frame_uniforms(p, cam, W, H, f_, True, nodes.shape[0], tris.shape[0]) for f_ in range(3)]
+    monkeypatch.delenv("RT_Q2_CAP", raising=False)        # (the stress matrix sets it for the whole suite)
     with rt.Renderer(pipeline=rt.RT_PIPELINE_WAVEFRONT) as r:
         r.upload_bvh(nodes, tris); r.upload_env(faces); r.resize(W, H)
         for u in us:
