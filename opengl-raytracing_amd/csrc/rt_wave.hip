@@ -1883,9 +1883,9 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
     // per frame with half the pairs overflowing -- hence never a guess below the worst case).  Small launch sets take the worst case, no question asked of the device.
     const double &q2Share = w->pool ? w->pool->q2Frac : w->q2FracOwn;   // (live: updated behind this set's hit-count read-back, before a large set sizes its arena)
     bool predictQ2 = false;          // set for deferred sets below
+    const bool predictOn = !(getenv("RT_Q2_PREDICT") && atoi(getenv("RT_Q2_PREDICT")) == 0);   // RT_Q2_PREDICT=0: always the worst case, as in rounds 1-4 (A/B)
     auto n2_of = [&](size_t ch) -> size_t {
         const size_t worst = ch * (size_t)SPP;
-        static const bool predictOn = !(getenv("RT_Q2_PREDICT") && atoi(getenv("RT_Q2_PREDICT")) == 0);   // RT_Q2_PREDICT=0: always the worst case, as in rounds 1-4 (A/B)
         size_t n2 = (predictOn && predictQ2 && q2Share > 0.0) ? std::max<size_t>((size_t)(2.0 * q2Share * (double)worst) + 65536, worst / 32) : worst;
         if (const char *e = getenv("RT_Q2_CAP")) n2 = std::max<size_t>((size_t)atoll(e), 64);   // tests: force the overflow path
         return align_up(std::min(n2, worst), 64);
@@ -1910,7 +1910,7 @@ int rt_wave_render(RtWave *w, RtContext *ctx, hipStream_t st, const DevFrame *dF
             // seven-frame batches of the timed region then had to grow again (a device-wide synchronisation and a multi-gigabyte hipMalloc inside a 34 ms region:
             // 1.65 -> 1.81 ms per step).
             room = std::max(room, P.maxCh[a]);
-            if (P.bytes[a] < arena_bytes(ch) || (predictQ2 && q2Share > 0.0 && getenv("RT_Q2_PREDICT") == nullptr && P.bytes[a] > arena_bytes(room) + arena_bytes(room) / 2 + arena_bytes(room) / 10)) {
+            if (P.bytes[a] < arena_bytes(ch) || (predictOn && predictQ2 && q2Share > 0.0 && P.bytes[a] > arena_bytes(room) + arena_bytes(room) / 2 + arena_bytes(room) / 10)) {
                 if (P.lastUser[a]) W_TRY(hipEventSynchronize(P.freeEv[a]));
                 if (P.mem[a]) (void)hipFree(P.mem[a]);
                 P.mem[a] = nullptr; P.bytes[a] = 0;
