@@ -110,3 +110,32 @@ def test_builder_boxes_are_unions_of_their_childrens():
     lo = np.minimum(nodes[left[inner], 0:3], nodes[right[inner], 0:3])
     hi = np.maximum(nodes[left[inner], 4:7], nodes[right[inner], 4:7])
     assert np.array_equal(lo, nodes[inner, 0:3]) and np.array_equal(hi, nodes[inner, 4:7])
+
+
+def test_implicit_records_preorder_address():
+    """The address arithmetic of the implicit records (csrc/rt_api.hip "implicit records", csrc/rt_wave.hip k_trace<.., IMPL>): in a perfect binary tree whose leaves sit at
+    depth D, the inner node reached by the left / right turns p (as a binary number, d bits) at depth d has the pre-order position  d - popcount(p) + (p << (D - d))  among
+    the inner nodes -- a left child sits next to its parent, a right child behind the whole left subtree -- and the positions of all inner nodes are a permutation of
+    0 .. 2^D - 2.  Checked against an explicit pre-order walk."""
+    for D in range(1, 9):
+        want = {}
+        counter = [0]
+
+        def walk(d, p):
+            if d == D:
+                return
+            want[(d, p)] = counter[0]
+            counter[0] += 1
+            walk(d + 1, 2 * p)
+            walk(d + 1, 2 * p + 1)
+
+        walk(0, 0)
+        assert counter[0] == (1 << D) - 1
+        got = {(d, p): d - bin(p).count("1") + (p << (D - d)) for (d, p) in want}
+        assert got == want, D
+        assert sorted(got.values()) == list(range((1 << D) - 1))
+        # four-wide form: the even-depth nodes keep their binary pre-order position (odd-depth slots of the array stay empty), children (d + 2, 4p + j)
+        for (d, p), at in want.items():
+            if d % 2 == 0 and d + 2 < D:
+                for j in range(4):
+                    assert (d + 2, 4 * p + j) in want
